@@ -1,0 +1,69 @@
+"""The oracle's model restatement against the REFERENCE's own outputs (golden fixtures)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle.model import OracleDeepSpeech, conv_out_time, gru_direction_explicit, seeded_state_dict
+from tests.golden.make_golden import seeded_inputs, seeded_labels
+
+
+def _run(golden_dir, name, kwargs, bsz, t_in, lengths, label_lens):
+    g = np.load(os.path.join(golden_dir, name))
+    model = OracleDeepSpeech(**kwargs)
+    model.load_state_dict(seeded_state_dict(model, 1234))
+    x = torch.from_numpy(seeded_inputs(77, bsz, t_in, lengths=lengths))
+    model.train()
+    logits, inter = model(x, return_intermediates=True)
+    assert logits.shape[1] == conv_out_time(t_in)
+    np.testing.assert_allclose(logits.detach().numpy(), g['logits'], rtol=0, atol=2e-5)
+    labels = seeded_labels(78, label_lens, 29)
+    loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), torch.from_numpy(labels).long(),
+                      torch.from_numpy(g['out_sizes']).long(), torch.tensor(label_lens), blank=0, reduction='sum')
+    assert abs(loss.item() - float(g['loss_sum'])) <= 1e-4 * abs(float(g['loss_sum']))
+    (loss / bsz).backward()
+    for k, p in model.named_parameters():
+        gn = np.sqrt((p.grad.numpy().astype(np.float64) ** 2).sum())
+        assert abs(gn - float(g['gnorm_' + k])) <= 1e-4 * float(g['gnorm_' + k]) + 1e-7, k
+        if 'grad_' + k in g:
+            np.testing.assert_allclose(p.grad.numpy(), g['grad_' + k], rtol=1e-3, atol=1e-5)
+    for k, v in model.state_dict().items():
+        if 'running' in k:
+            np.testing.assert_allclose(v.numpy(), g['buf_' + k], rtol=1e-5, atol=1e-6)
+    model.eval()
+    with torch.no_grad():
+        probs = model(x)
+    np.testing.assert_allclose(probs.numpy(), g['probs'], rtol=0, atol=1e-5)
+    return g, inter
+
+
+def test_tiny_model_matches_reference(golden_dir):
+    g, inter = _run(golden_dir, 'ref_tiny.npz', dict(rnn_hidden_size=32, num_rnn_layers=2), 3, 121,
+                    [121, 97, 64], [9, 6, 4])
+    for k in ('conv1', 'conv2', 'rnn0', 'rnn1'):
+        np.testing.assert_allclose(inter[k].detach().numpy(), g['inter_' + k], rtol=0, atol=2e-5)
+
+
+def test_full_model_matches_reference(golden_dir):
+    _run(golden_dir, 'ref_full.npz', dict(), 2, 301, [301, 233], [30, 21])
+
+
+def test_state_dict_keys_are_the_reference_names(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ref_full.npz'))
+    ref_params = sorted(k[len('gnorm_'):] for k in g.files if k.startswith('gnorm_'))
+    model = OracleDeepSpeech()
+    assert sorted(k for k, _ in model.named_parameters()) == ref_params
+    assert sum(p.numel() for p in model.parameters()) == 38067968
+
+
+def test_explicit_gru_equals_nn_gru():
+    torch.manual_seed(3)
+    t, b, n_in, h = 7, 3, 5, 4
+    gru = torch.nn.GRU(n_in, h, bidirectional=True, bias=False)
+    x = torch.randn(t, b, n_in)
+    y, _ = gru(x)
+    f = gru_direction_explicit(x, gru.weight_ih_l0, gru.weight_hh_l0)
+    r = gru_direction_explicit(x, gru.weight_ih_l0_reverse, gru.weight_hh_l0_reverse, reverse=True)
+    np.testing.assert_allclose(f['h'].detach().numpy(), y[:, :, :h].detach().numpy(), atol=1e-6)
+    np.testing.assert_allclose(r['h'].detach().numpy(), y[:, :, h:].detach().numpy(), atol=1e-6)
