@@ -1,0 +1,372 @@
+"""DeepSpeech2 (conv -> BiGRU -> FC) for MI355X: the reference's ``codes.model.DeepSpeech`` surface over
+hand-written HIP kernels.
+
+Drop-in contract (reference ``codes/model.py:116-207``):
+  * same constructor keywords (``:119-127``), same ``forward(x: (B,T_in,161)) -> (B,T,num_classes)``:
+    un-normalised activations in training mode, softmax in eval mode (``:201-205``);
+  * same ``state_dict()`` key names and shapes, so checkpoints interchange by name
+    (``codes/utils/model_utils.py:70``): ``conv.{0,3}.{weight,bias}``, ``conv.{1,4}.*``,
+    ``rnns.N.rnn.weight_{ih,hh}_l0[_reverse]``, ``rnns.N.batch_norm.module.*``, ``fc.0.module.{0,1}.*``;
+  * same arithmetic quirks: no sequence packing (``:62``), BatchNorm over padded frames (``:59-60``),
+    directions summed (``:64-67``), time padding on conv1 only (``:143-144``).
+
+What differs is underneath: every tensor op is a kernel of libds2hip.so (``include/ds2hip.h``).  The
+modules below only HOLD parameters under the reference's names; none of them has a PyTorch forward.
+Parameters live in one flat fp32 buffer (views), laid out so that both directions' W_ih (and W_hh)
+of a layer are adjacent: one MFMA GEMM produces the gate pre-activations of both directions and one
+fused kernel applies clip + Nesterov SGD to everything.
+
+Out of scope: unidirectional + Lookahead, LSTM/RNN cells, multi-task heads.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from ds2hip import ops
+
+
+# ------------------------------------------------------------------------------------ parameter holders
+class _Conv2dParams(nn.Module):
+    """weight (Cout,Cin,KF,KT) + bias, initialised like torch.nn.Conv2d.reset_parameters."""
+
+    def __init__(self, cin, cout, kf, kt):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, kf, kt))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(cin * kf * kt)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _BatchNormParams(nn.Module):
+    def __init__(self, num_features):
+        super().__init__()
+        self.num_features = num_features
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+
+class _Placeholder(nn.Module):
+    """Keeps the reference's Sequential indices (Hardtanh slots hold no parameters)."""
+
+
+class _GRUParams(nn.Module):
+    """weight_{ih,hh}_l0[_reverse], gate order r,z,n, initialised like torch.nn.GRU (uniform +-1/sqrt(H))."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        k = 1.0 / math.sqrt(hidden_size)
+        for suffix in ('', '_reverse'):
+            for nm, cols in (('weight_ih_l0', input_size), ('weight_hh_l0', hidden_size)):
+                p = nn.Parameter(torch.empty(3 * hidden_size, cols))
+                nn.init.uniform_(p, -k, k)
+                self.register_parameter(nm + suffix, p)
+
+
+class _LinearParams(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+
+class SequenceWise(nn.Module):
+    """Holder named like the reference's SequenceWise (codes/model.py:13-34): ``.module``."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+class BatchRNN(nn.Module):
+    """Holder named like the reference's BatchRNN (codes/model.py:43-69): ``.batch_norm.module``, ``.rnn``."""
+
+    def __init__(self, input_size, hidden_size, batch_norm=True):
+        super().__init__()
+        self.batch_norm = SequenceWise(_BatchNormParams(input_size)) if batch_norm else None
+        self.rnn = _GRUParams(input_size, hidden_size)
+
+
+# ------------------------------------------------------------------------------------ autograd bridge
+class _DS2Function(torch.autograd.Function):
+    """Whole-network forward/backward as ONE autograd node, so ``loss.backward()`` works as in the reference."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        acts, saved = model._forward_impl(x, training=True, need_grad=True)
+        ctx.model, ctx.saved = model, saved
+        return acts
+
+    @staticmethod
+    def backward(ctx, d_acts):
+        model = ctx.model
+        gflat = torch.empty_like(model._flat_p)
+        model._backward_impl(ctx.saved, d_acts.contiguous(), gflat)
+        ctx.saved = None
+        grads = [gflat[o:o + p.numel()].view_as(p) for p, o in zip(model._plist, model._offsets)]
+        return (None, None) + tuple(grads)
+
+
+class DeepSpeech(nn.Module):
+    __version__ = '0.0.1'
+
+    def __init__(self, rnn_type=nn.GRU, num_classes=29, rnn_hidden_size=800, num_rnn_layers=5, window_size=320,
+                 bidirectional=True, context=20, include_classifier=True):
+        super().__init__()
+        if isinstance(rnn_type, str):
+            rnn_type = getattr(torch.nn, rnn_type.upper())
+        if rnn_type is not nn.GRU or not bidirectional or not include_classifier:
+            raise NotImplementedError('the MI355X path implements the bidirectional-GRU classifier model only '
+                                      '(every BASELINE config); see SURVEY.md section 2 row 1')
+        if rnn_hidden_size % 8 != 0:
+            raise ValueError('rnn_hidden_size must be a multiple of 8')
+        self._rnn_type = rnn_type
+        self._num_classes = num_classes
+        self._rnn_hidden_size = rnn_hidden_size
+        self._num_rnn_layers = num_rnn_layers
+        self._window_size = window_size
+        self._bidirectional = bidirectional
+        self._context = context
+        self._include_classifier = include_classifier
+
+        self.conv = nn.Sequential(_Conv2dParams(1, 32, 41, 11), _BatchNormParams(32), _Placeholder(),
+                                  _Conv2dParams(32, 32, 21, 11), _BatchNormParams(32), _Placeholder())
+        feat = window_size // 2 + 1
+        feat = (feat - 41) // 2 + 1
+        feat = (feat - 21) // 2 + 1
+        if window_size != 320:
+            raise NotImplementedError('conv kernels are specialised for 161 frequency bins (window_size=320)')
+        self._rnn_input_size = 32 * feat
+        rnns = [('0', BatchRNN(self._rnn_input_size, rnn_hidden_size, batch_norm=False))]
+        for i in range(num_rnn_layers - 1):
+            rnns.append((str(i + 1), BatchRNN(rnn_hidden_size, rnn_hidden_size)))
+        self.rnns = nn.Sequential(OrderedDict(rnns))
+        self.lookahead = None
+        self.fc = nn.Sequential(SequenceWise(nn.Sequential(_BatchNormParams(rnn_hidden_size),
+                                                           _LinearParams(rnn_hidden_size, num_classes))))
+        self._flat_p = None
+        self._flat_g = None
+        self._plist, self._offsets = [], []
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _flat_order(self):
+        c = self.conv
+        order = [c[0].weight, c[0].bias, c[1].weight, c[1].bias, c[3].weight, c[3].bias, c[4].weight, c[4].bias]
+        for layer in self.rnns:
+            if layer.batch_norm is not None:
+                order += [layer.batch_norm.module.weight, layer.batch_norm.module.bias]
+            r = layer.rnn
+            order += [r.weight_ih_l0, r.weight_ih_l0_reverse, r.weight_hh_l0, r.weight_hh_l0_reverse]
+        head = self.fc[0].module
+        order += [head[0].weight, head[0].bias, head[1].weight]
+        return order
+
+    def flatten_parameters(self):
+        """(Re)pack every parameter into one contiguous fp32 buffer; parameters become views of it."""
+        order = self._flat_order()
+        dev = order[0].device
+        offsets, n = [], 0
+        for p in order:
+            offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(order, offsets):
+                flat[o:o + p.numel()].copy_(p.detach().reshape(-1).to(device=dev, dtype=torch.float32))
+                p.data = flat[o:o + p.numel()].view(p.shape)
+        self._flat_p, self._plist, self._offsets = flat, order, offsets
+        self._flat_g = None
+        return self
+
+    def _ensure_flat(self):
+        order = self._flat_order()
+        ok = self._flat_p is not None and len(order) == len(self._plist)
+        if ok:
+            base = self._flat_p.data_ptr()
+            for p, q, o in zip(order, self._plist, self._offsets):
+                if p is not q or p.data_ptr() != base + 4 * o:
+                    ok = False
+                    break
+        if not ok:
+            self.flatten_parameters()
+
+    def flat_grad(self):
+        """Persistent flat gradient buffer; each parameter's .grad is a view of it."""
+        self._ensure_flat()
+        if self._flat_g is None or self._flat_g.device != self._flat_p.device:
+            self._flat_g = torch.zeros_like(self._flat_p)
+            for p, o in zip(self._plist, self._offsets):
+                p.grad = self._flat_g[o:o + p.numel()].view(p.shape)
+        return self._flat_g
+
+    def _gview(self, gflat, p):
+        for q, o in zip(self._plist, self._offsets):
+            if q is p:
+                return gflat[o:o + p.numel()].view(p.shape)
+        raise KeyError('parameter not in flat buffer')
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        dev = self.conv[0].weight.device
+        if dev.type != 'cuda':
+            raise RuntimeError('DeepSpeech runs on a ROCm device only (model.to("cuda")); there is no CPU path')
+        if x.device != dev:            # the reference hands CPU batches to DataParallel (codes/engine.py:58)
+            x = x.to(dev)
+        x = x.contiguous().float()
+        self._ensure_flat()
+        if self.training and torch.is_grad_enabled():
+            acts = _DS2Function.apply(self, x, *self._plist)
+        else:
+            acts, _ = self._forward_impl(x, training=self.training, need_grad=False)
+        out = acts.transpose(0, 1)                                   # (B,T,A) view, as codes/model.py:201
+        if not self.training:
+            t, b, a = acts.shape
+            out = ops.softmax_rows(acts.view(t * b, a), t * b, a).view(t, b, a).transpose(0, 1)
+        return out
+
+    def _forward_impl(self, x, training, need_grad):
+        """x (B,T_in,161) -> acts (T,B,A); returns the tensors backward needs."""
+        bsz, t_in, nfreq = x.shape
+        assert nfreq == 161, 'expected 161 frequency bins'
+        hid, nlayers = self._rnn_hidden_size, self._num_rnn_layers
+        t1, t = ops.conv_out_frames(t_in)
+        assert t > 0, 'input too short for the conv stack'
+        sv = {'t_in': t_in, 't1': t1, 't': t, 'bsz': bsz}
+        c = self.conv
+        xt = ops.transpose_btf(x)                                                   # (B,161,T_in)
+        y1 = ops.conv_fwd(1, xt, c[0].weight, c[0].bias, t_in)                      # (B,32,61,T1)
+        mi1 = ops.bn2d_stats(y1, c[1].running_mean, c[1].running_var, training)
+        a1 = ops.bn2d_apply_htanh(y1, mi1, c[1].weight, c[1].bias, layout_tbf=False)
+        y2 = ops.conv_fwd(2, a1, c[3].weight, c[3].bias, t1)                        # (B,32,21,T)
+        mi2 = ops.bn2d_stats(y2, c[4].running_mean, c[4].running_var, training)
+        xin = ops.bn2d_apply_htanh(y2, mi2, c[4].weight, c[4].bias, layout_tbf=True)  # (T,B,672)
+        if training:
+            c[1].num_batches_tracked += 1
+            c[4].num_batches_tracked += 1
+        sv.update(xt=xt, y1=y1, mi1=mi1, a1=a1, y2=y2, mi2=mi2)
+        rows = t * bsz
+        layers = []
+        prev_h = None
+        for li, layer in enumerate(self.rnns):
+            n_in = self._rnn_input_size if li == 0 else hid
+            rec = {}
+            if layer.batch_norm is not None:
+                bn = layer.batch_norm.module
+                mi = ops.bn1d_stats(prev_h[0], prev_h[1], rows, hid, bn.running_mean, bn.running_var, training)
+                xin = ops.bn1d_apply(prev_h[0], prev_h[1], mi, bn.weight, bn.bias, rows, hid)
+                if training:
+                    bn.num_batches_tracked += 1
+                rec['mi'] = mi
+            r = layer.rnn
+            w_ih = self._pair(r.weight_ih_l0, r.weight_ih_l0_reverse)               # (6H, In) view
+            w_hh = self._pair(r.weight_hh_l0, r.weight_hh_l0_reverse)               # (2*3H, H) view
+            gates = ops.gemm(xin.view(rows, n_in), w_ih, trans_b=True)              # (T*B, 6H)
+            ghn, hout = ops.gru_bidir_fwd(gates, w_hh, t, bsz, hid)
+            rec.update(xin=xin, gates=gates, ghn=ghn, hout=hout)
+            layers.append(rec)
+            prev_h = hout
+        head = self.fc[0].module
+        mi = ops.bn1d_stats(prev_h[0], prev_h[1], rows, hid, head[0].running_mean, head[0].running_var, training)
+        xf = ops.bn1d_apply(prev_h[0], prev_h[1], mi, head[0].weight, head[0].bias, rows, hid)
+        if training:
+            head[0].num_batches_tracked += 1
+        acts = ops.gemm(xf, head[1].weight, trans_b=True).view(t, bsz, self._num_classes)
+        sv.update(layers=layers, mi_fc=mi, xf=xf)
+        return acts, (sv if need_grad else None)
+
+    def _pair(self, p_fwd, p_rev):
+        """The two directions' weights are adjacent in the flat buffer: return them as one (2*rows, cols) matrix."""
+        n = p_fwd.numel()
+        assert p_rev.data_ptr() == p_fwd.data_ptr() + 4 * n, 'flat layout broken; call flatten_parameters()'
+        off = (p_fwd.data_ptr() - self._flat_p.data_ptr()) // 4
+        return self._flat_p[off:off + 2 * n].view(2 * p_fwd.shape[0], p_fwd.shape[1])
+
+    # ------------------------------------------------------------------ backward
+    def _backward_impl(self, sv, d_acts, gflat):
+        """d_acts (T,B,A) -> gradients of every parameter written into ``gflat`` (same layout as the flat params)."""
+        hid, ncls = self._rnn_hidden_size, self._num_classes
+        t, bsz, t1, t_in = sv['t'], sv['bsz'], sv['t1'], sv['t_in']
+        rows = t * bsz
+        gv = lambda p: self._gview(gflat, p)                                        # noqa: E731
+        head = self.fc[0].module
+        d2 = d_acts.reshape(rows, ncls)
+        ops.gemm(d2, sv['xf'], trans_a=True, out=gv(head[1].weight))               # dW_fc = d^T xf
+        dxf = ops.gemm(d2, head[1].weight)                                          # (rows,H)
+        last = sv['layers'][-1]['hout']
+        dy = ops.bn1d_bwd(last[0], last[1], dxf, sv['mi_fc'], head[0].weight, rows, hid, gv(head[0].weight),
+                          gv(head[0].bias))
+        nl = len(sv['layers'])
+        f4 = 4
+        for li in range(nl - 1, -1, -1):
+            rec = sv['layers'][li]
+            layer = self.rnns[li]
+            r = layer.rnn
+            n_in = self._rnn_input_size if li == 0 else hid
+            w_ih = self._pair(r.weight_ih_l0, r.weight_ih_l0_reverse)
+            w_hh = self._pair(r.weight_hh_l0, r.weight_hh_l0_reverse).view(2, 3 * hid, hid)
+            w_hh_t = torch.empty((2, hid, 3 * hid), dtype=torch.float32, device=gflat.device)
+            ops.transpose2d(w_hh[0], 3 * hid, hid, out=w_hh_t[0])
+            ops.transpose2d(w_hh[1], 3 * hid, hid, out=w_hh_t[1])
+            gates, ghn, hout = rec['gates'], rec['ghn'], rec['hout']
+            ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid)           # gates -> d(gi), ghn -> d(gh_n)
+            # dW_hh[d] = dGH[d]^T h_prev[d]; forward dir pairs step t with h[t-1], reverse with h[t+1]
+            g_hh = (gv(r.weight_hh_l0), gv(r.weight_hh_l0_reverse))
+            if t > 1:
+                k = (t - 1) * bsz
+                step_g, step_n = bsz * 6 * hid * f4, bsz * 2 * hid * f4
+                for d in (0, 1):
+                    a_g = gates.data_ptr() + d * 3 * hid * f4 + (step_g if d == 0 else 0)
+                    a_n = ghn.data_ptr() + d * hid * f4 + (step_n if d == 0 else 0)
+                    hp = hout[d].data_ptr() + (0 if d == 0 else bsz * hid * f4)
+                    ops.gemm_raw(1, 0, 2 * hid, hid, k, a_g, 6 * hid, hp, hid, g_hh[d].data_ptr(), hid)
+                    ops.gemm_raw(1, 0, hid, hid, k, a_n, 2 * hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4, hid)
+            else:
+                g_hh[0].zero_()
+                g_hh[1].zero_()
+            dgi = gates.view(rows, 6 * hid)
+            g_ih = self._pair_view(gflat, r.weight_ih_l0, r.weight_ih_l0_reverse)
+            ops.gemm(dgi, rec['xin'].view(rows, n_in), trans_a=True, out=g_ih)      # dW_ih (both dirs)
+            dxin = ops.gemm(dgi, w_ih)                                              # (rows, n_in)
+            if layer.batch_norm is not None:
+                bn = layer.batch_norm.module
+                below = sv['layers'][li - 1]['hout']
+                dy = ops.bn1d_bwd(below[0], below[1], dxin, rec['mi'], bn.weight, rows, hid, gv(bn.weight),
+                                  gv(bn.bias))
+            else:
+                dy = dxin
+            rec.clear()
+        c = self.conv
+        d_a2 = ops.transpose2d(dy, t, bsz * self._rnn_input_size).view(bsz, 32, 21, t)   # (T,B,672) -> (B,32,21,T)
+        d_y2 = ops.bn2d_htanh_bwd(sv['y2'], d_a2, sv['mi2'], c[4].weight, c[4].bias, gv(c[4].weight), gv(c[4].bias))
+        ops.conv_wgrad(2, sv['a1'], d_y2, t1, gv(c[3].weight), gv(c[3].bias))
+        d_a1 = ops.conv2_dgrad(d_y2, c[3].weight, t1)
+        d_y1 = ops.bn2d_htanh_bwd(sv['y1'], d_a1, sv['mi1'], c[1].weight, c[1].bias, gv(c[1].weight), gv(c[1].bias))
+        ops.conv_wgrad(1, sv['xt'], d_y1, t_in, gv(c[0].weight), gv(c[0].bias))
+
+    def _pair_view(self, gflat, p_fwd, p_rev):
+        n = p_fwd.numel()
+        off = (p_fwd.data_ptr() - self._flat_p.data_ptr()) // 4
+        return gflat[off:off + 2 * n].view(2 * p_fwd.shape[0], p_fwd.shape[1])
+
+    # ------------------------------------------------------------------ training fast path (no autograd)
+    def forward_backward(self, x, loss_fn):
+        """One fused pass for the trainer: acts -> ``loss_fn(acts) -> (loss, d_acts)`` -> gradients into flat_grad().
+
+        Mirrors model(inputs) + criterion + backward of codes/engine.py:62-84 without building an autograd graph.
+        """
+        dev = self.conv[0].weight.device
+        if x.device != dev:
+            x = x.to(dev)
+        self._ensure_flat()
+        gflat = self.flat_grad()
+        acts, sv = self._forward_impl(x.contiguous().float(), training=True, need_grad=True)
+        loss, d_acts = loss_fn(acts)
+        self._backward_impl(sv, d_acts, gflat)
+        return loss, acts

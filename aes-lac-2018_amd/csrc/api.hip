@@ -1,0 +1,16 @@
+// Error reporting + version for libds2hip.so.
+#include <stdarg.h>
+
+#include "ds2_common.h"
+
+static thread_local char g_err[512] = "";
+
+void ds2_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ds2_last_error(void) { return g_err; }
+extern "C" int ds2_version(void) { return 100; }

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Build libds2hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python aes-lac-2018_amd/csrc/build.py [--force] [-v]
+
+Each .hip file is compiled to an object (cached by mtime) and linked into
+aes-lac-2018_amd/ds2hip/libds2hip.so.  The .so is git-ignored but travels to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+OUT = os.path.join(PKG, 'ds2hip', 'libds2hip.so')
+OBJ = os.path.join(HERE, 'build')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', HERE,
+         '-Wall', '-Wno-unused-function']
+
+
+def _newer(src, dst, deps):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in [src] + deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
+    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
+    deps.append(os.path.join(ROOT, 'include', 'ds2hip.h'))
+    jobs = []
+    objs = []
+    for s in srcs:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(OBJ, s[:-4] + '.o')
+        objs.append(obj)
+        if force or _newer(src, obj, deps):
+            jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s\n%s' % (' '.join(cmd), r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or not os.path.exists(OUT):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))

@@ -1,0 +1,290 @@
+// Direct (im2col-free) 2-D convolutions of the DeepSpeech2 front stack on the f32 MFMA, gfx950.
+//
+// Layout: NCHW with TIME innermost, so that the MFMA operand that walks output time steps is a
+// contiguous (stride-1 or stride-2) window of an input row -- no im2col matrix ever exists.
+//
+//   forward   D[co][t]  += Wt[k][co] * in[b][ci][SF*d+kf][ST*t+kt-PADT]      k = (ci,kf,kt)
+//   dgrad     D[ci][t1] += Wd[k][ci] * dout[b][co][(f-kf)/2][t1-kt]          k = (co,kf,kt), kf = f (mod 2)
+//   wgrad     D[co][n]  += dout[b][co][d][t] * in[b][ci][SF*d+kf][ST*t+kt-PADT], n = (ci,kf,kt), k = (b,d,t)
+//
+// v_mfma_f32_32x32x2_f32: lanes 0-31 feed k even, lanes 32-63 k odd.  The 11 time taps are padded
+// to 12 (tap 11 has zero weight) so that a k pair never straddles a filter row; the filter is
+// re-laid-out once per call into [.. k ..][32] so the A fetch is one coalesced 128-B read per
+// half-wave.  One wave = one 32 x (32*NT) output tile; 4 independent waves per workgroup walk
+// neighbouring frequency rows so their input windows overlap in L1/L2.
+#include "ds2_common.h"
+
+namespace {
+
+constexpr int KTP = 12;  // padded time taps
+
+// ---------------------------------------------------------------------------- filter re-layout
+// mode 0 (forward):  wt[((ci*KF+kf)*12+kt)*32 + co] = w[((co*CIN+ci)*KF+kf)*KT+kt]
+// mode 1 (dgrad):    wt[((co*KF+kf)*12+kt)*32 + ci] = w[((co*CIN+ci)*KF+kf)*KT+kt]   (CIN = 32)
+__global__ __launch_bounds__(256) void conv_wt_layout_kernel(const float* __restrict__ w, int CIN, int KF, int KT,
+                                                             int mode, float* __restrict__ wt) {
+    const int total = (mode == 0 ? CIN : 32) * KF * KTP * 32;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int x = i & 31;
+        int r = i >> 5;
+        const int kt = r % KTP;
+        r /= KTP;
+        const int kf = r % KF;
+        const int y = r / KF;
+        const int co = mode == 0 ? x : y, ci = mode == 0 ? y : x;
+        wt[i] = kt < KT ? w[(((size_t)co * CIN + ci) * KF + kf) * KT + kt] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------- forward
+template <int CIN, int KF, int SF, int ST, int PADT, int NT>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                       const float* __restrict__ bias, int B, int FIN, int TIN,
+                                                       int FOUT, int TOUT, int ttiles, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const long tile = (long)blockIdx.x * 4 + wave;
+    const long ntiles = (long)B * ttiles * FOUT;
+    if (tile >= ntiles) return;
+    const int d = (int)(tile % FOUT);
+    const int tt = (int)((tile / FOUT) % ttiles);
+    const int b = (int)(tile / ((long)FOUT * ttiles));
+    const int t0 = tt * 32 * NT;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // time index of this lane's output column for tap 0 (per N tile)
+    int tbase[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) tbase[i] = ST * (t0 + 32 * i + lr) - PADT + lh;
+
+    const float* wp = wt + lh * 32 + lr;
+    for (int ci = 0; ci < CIN; ++ci) {
+        const float* rowbase = in + (((size_t)b * CIN + ci) * FIN + (size_t)SF * d) * TIN;
+        for (int kf = 0; kf < KF; ++kf) {
+            const float* row = rowbase + (size_t)kf * TIN;
+#pragma unroll
+            for (int kp = 0; kp < KTP / 2; ++kp) {
+                const float a = wp[kp * 64];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int ti = tbase[i] + 2 * kp;
+                    const float v = (ti >= 0 && ti < TIN) ? row[ti] : 0.f;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[i], 0, 0, 0);
+                }
+            }
+            wp += KTP * 32;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = t0 + 32 * i + lr;
+        if (t >= TOUT) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[(((size_t)b * 32 + co) * FOUT + d) * TOUT + t] = acc[i][r] + bias[co];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- conv2 dgrad
+// d_in (B,32,FIN,T1) from d_out (B,32,FOUT,T); kernel (32,32,KF,11), stride (2,1), no padding
+template <int KF, int NT>
+__global__ __launch_bounds__(256) void conv2_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ wd,
+                                                          int B, int FIN, int T1, int FOUT, int T, int ttiles,
+                                                          float* __restrict__ din) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const long tile = (long)blockIdx.x * 4 + wave;
+    const long ntiles = (long)B * ttiles * FIN;
+    if (tile >= ntiles) return;
+    const int f = (int)(tile % FIN);
+    const int tt = (int)((tile / FIN) % ttiles);
+    const int b = (int)(tile / ((long)FIN * ttiles));
+    const int t0 = tt * 32 * NT;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    int tbase[NT];  // t1 - kt with kt = 2*kp + lh
+#pragma unroll
+    for (int i = 0; i < NT; ++i) tbase[i] = t0 + 32 * i + lr - lh;
+
+    for (int co = 0; co < 32; ++co) {
+        for (int kf = (f & 1); kf < KF; kf += 2) {
+            const int d = (f - kf) >> 1;
+            if (d < 0 || d >= FOUT) continue;
+            const float* row = dout + (((size_t)b * 32 + co) * FOUT + d) * T;
+            const float* wp = wd + ((size_t)(co * KF + kf) * KTP) * 32 + lh * 32 + lr;
+#pragma unroll
+            for (int kp = 0; kp < KTP / 2; ++kp) {
+                const float a = wp[kp * 64];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int ti = tbase[i] - 2 * kp;
+                    const float v = (ti >= 0 && ti < T) ? row[ti] : 0.f;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int t = t0 + 32 * i + lr;
+        if (t >= T1) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            din[(((size_t)b * 32 + ci) * FIN + f) * T1 + t] = acc[i][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- wgrad
+// grid (ntiles_n, splits); one wave per workgroup slot: block = 256 threads = 4 waves, each wave
+// takes every 4th (b,d) row of its split.  Results are atomically added into dW (zeroed by the host
+// wrapper) -- float atomics make the last bits order-dependent.
+template <int CIN, int KF, int KT, int SF, int ST, int PADT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                         int B, int FIN, int TIN, int FOUT, int TOUT, int nsplit,
+                                                         float* __restrict__ dw, float* __restrict__ dbias) {
+    constexpr int NTOT = CIN * KF * KT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int n = blockIdx.x * 32 + lr;
+    const bool n_ok = n < NTOT;
+    const int nn = n_ok ? n : 0;
+    const int kt = nn % KT, kf = (nn / KT) % KF, ci = nn / (KT * KF);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+
+    const int rows = B * FOUT;
+    for (int row = blockIdx.y * 4 + wave; row < rows; row += nsplit * 4) {
+        const int b = row / FOUT, d = row % FOUT;
+        const float* ap = dout + (((size_t)b * 32 + lr) * FOUT + d) * TOUT;
+        const float* bp = in + (((size_t)b * CIN + ci) * FIN + (size_t)SF * d + kf) * TIN;
+        for (int t0 = 0; t0 < TOUT; t0 += 8) {
+            const int t = t0 + 4 * lh;
+            float a[4], v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = (t + e < TOUT) ? ap[t + e] : 0.f;
+                const int ti = ST * (t + e) + kt - PADT;
+                v[e] = (n_ok && t + e < TOUT && ti >= 0 && ti < TIN) ? bp[ti] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], v[e], acc, 0, 0, 0);
+                bsum += a[e];
+            }
+        }
+    }
+    if (n_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            atomicAdd(&dw[(size_t)co * NTOT + n], acc[r]);
+        }
+    }
+    if (blockIdx.x == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lh == 0) atomicAdd(&dbias[lr], bsum);
+    }
+}
+
+struct ConvGeom {
+    int cin, kf, kt, sf, st, padt, fin, fout;
+};
+inline ConvGeom geom(int which) {
+    if (which == 1) return {1, 41, 11, 2, 2, 10, 161, 61};
+    return {32, 21, 11, 2, 1, 0, 61, 21};
+}
+inline int conv_tout(int which, int tin) { return which == 1 ? (tin + 20 - 11) / 2 + 1 : tin - 10; }
+
+}  // namespace
+
+extern "C" size_t ds2_conv_wt_ws_floats(int which) {
+    const ConvGeom g = geom(which);
+    return (size_t)32 * g.kf * KTP * 32 > (size_t)g.cin * g.kf * KTP * 32 ? (size_t)32 * g.kf * KTP * 32
+                                                                          : (size_t)g.cin * g.kf * KTP * 32;
+}
+
+extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, const float* bias, int B,
+                            int t_in_frames, float* out, float* wt_ws, void* stream) {
+    DS2_CHECK_ARG(which == 1 || which == 2);
+    DS2_CHECK_ARG(in && weight && bias && out && wt_ws && B > 0);
+    const ConvGeom g = geom(which);
+    const int tin = t_in_frames, tout = conv_tout(which, tin);
+    DS2_CHECK_ARG(tout > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int total = g.cin * g.kf * KTP * 32;
+    hipLaunchKernelGGL(conv_wt_layout_kernel, dim3(ds2_cdiv(total, 256)), dim3(256), 0, st, weight, g.cin, g.kf, g.kt,
+                       0, wt_ws);
+    constexpr int NT = 2;
+    const int ttiles = ds2_cdiv(tout, 32 * NT);
+    const long ntiles = (long)B * ttiles * g.fout;
+    dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
+    if (which == 1)
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 41, 2, 2, 10, NT>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
+                           g.fout, tout, ttiles, out);
+    else
+        hipLaunchKernelGGL((conv_fwd_kernel<32, 21, 2, 1, 0, NT>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
+                           g.fout, tout, ttiles, out);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}
+
+extern "C" int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, int T1, float* d_in, float* wt_ws,
+                               void* stream) {
+    DS2_CHECK_ARG(d_out && weight && d_in && wt_ws && B > 0 && T1 > 10);
+    hipStream_t st = (hipStream_t)stream;
+    const int T = T1 - 10;
+    const int total = 32 * 21 * KTP * 32;
+    hipLaunchKernelGGL(conv_wt_layout_kernel, dim3(ds2_cdiv(total, 256)), dim3(256), 0, st, weight, 32, 21, 11, 1,
+                       wt_ws);
+    constexpr int NT = 2;
+    const int ttiles = ds2_cdiv(T1, 32 * NT);
+    const long ntiles = (long)B * ttiles * 61;
+    hipLaunchKernelGGL((conv2_dgrad_kernel<21, NT>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d_out, wt_ws,
+                       B, 61, T1, 21, T, ttiles, d_in);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}
+
+extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, int B, int t_in_frames, float* d_weight,
+                              float* d_bias, void* stream) {
+    DS2_CHECK_ARG(which == 1 || which == 2);
+    DS2_CHECK_ARG(in && d_out && d_weight && d_bias && B > 0);
+    const ConvGeom g = geom(which);
+    const int tin = t_in_frames, tout = conv_tout(which, tin);
+    DS2_CHECK_ARG(tout > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int ntot = g.cin * g.kf * g.kt;
+    DS2_HIP(hipMemsetAsync(d_weight, 0, (size_t)32 * ntot * sizeof(float), st));
+    DS2_HIP(hipMemsetAsync(d_bias, 0, 32 * sizeof(float), st));
+    const int ntn = ds2_cdiv(ntot, 32);
+    const int rows = B * g.fout;
+    int nsplit = ds2_cdiv(2048, ntn);
+    if (nsplit > ds2_cdiv(rows, 4)) nsplit = ds2_cdiv(rows, 4);
+    if (nsplit < 1) nsplit = 1;
+    dim3 grid(ntn, nsplit), block(256);
+    if (which == 1)
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, 41, 11, 2, 2, 10>), grid, block, 0, st, in, d_out, B, g.fin, tin,
+                           g.fout, tout, nsplit, d_weight, d_bias);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<32, 21, 11, 2, 1, 0>), grid, block, 0, st, in, d_out, B, g.fin, tin,
+                           g.fout, tout, nsplit, d_weight, d_bias);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}

@@ -1,0 +1,60 @@
+// Shared helpers for the ds2hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "ds2hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// float4 with only 4-byte alignment: lets hipcc emit one dwordx4 for an unaligned window
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+void ds2_set_error(const char* fmt, ...);
+
+#define DS2_CHECK_ARG(cond)                                                        \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            ds2_set_error("%s: bad argument: %s", __func__, #cond);                \
+            return DS2_ERR_ARG;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define DS2_CHECK_LAUNCH()                                                         \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            ds2_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return DS2_ERR_LAUNCH;                                                 \
+        }                                                                          \
+    } while (0)
+
+#define DS2_HIP(call)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            ds2_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e_)); \
+            return DS2_ERR_LAUNCH;                                                 \
+        }                                                                          \
+    } while (0)
+
+static inline int ds2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -1,0 +1,207 @@
+// fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// C[M,N] = op(A) op(B) + beta C.  One 256-thread workgroup (4 waves, 2x2) computes a 128x128
+// tile; each wave owns 64x64 = 2x2 MFMA tiles of 32x32 (4 accumulators x 16 VGPRs).  K is
+// walked in 16-deep slabs staged through LDS in a k-major image ([k][m], [k][n]) so that
+// the MFMA operand fetch (lane l: A[m = l&31][k = l>>5]) is a conflict-free ds_read_b32 of
+// 32 consecutive floats per half-wave.  Global->register prefetch of slab k+1 overlaps the
+// MFMAs of slab k (double-buffered LDS, one barrier per slab).
+//
+// Operand source layouts (row-major, leading dimension ld):
+//   A "k-contiguous"  A[m*lda + k]   (trans_a = 0)     A "m-contiguous"  A[k*lda + m]  (trans_a = 1)
+//   B "n-contiguous"  B[k*ldb + n]   (trans_b = 0)     B "k-contiguous"  B[n*ldb + k]  (trans_b = 1)
+// Numerics: exact fp32 FMA chain in k order per 2-k MFMA (same as fmaf accumulation).
+#include "ds2_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDT = 132;  // LDS row pitch (floats): 16-B aligned rows, 2-way conflict at worst on writes
+
+// Stage one operand slab [BK][128] into registers.  KCONTIG: the source is X x K (x = m or n).
+template <bool KCONTIG, bool VEC>
+__device__ __forceinline__ void load_slab(const float* __restrict__ src, int ld, int x0, int xmax, int k0,
+                                          int kmax, int tid, f32x4 (&r)[2]) {
+    if (KCONTIG) {
+        const int kq = (tid & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int x = x0 + (tid >> 2) + 64 * i;
+            const int k = k0 + kq;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (x < xmax) {
+                const float* p = src + (size_t)x * ld + k;
+                if (VEC && k + 3 < kmax) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (k + 0 < kmax) v[0] = p[0];
+                    if (k + 1 < kmax) v[1] = p[1];
+                    if (k + 2 < kmax) v[2] = p[2];
+                    if (k + 3 < kmax) v[3] = p[3];
+                }
+            }
+            r[i] = v;
+        }
+    } else {
+        const int xq = (tid & 31) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + (tid >> 5) + 8 * i;
+            const int x = x0 + xq;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < kmax) {
+                const float* p = src + (size_t)k * ld + x;
+                if (VEC && x + 3 < xmax) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (x + 0 < xmax) v[0] = p[0];
+                    if (x + 1 < xmax) v[1] = p[1];
+                    if (x + 2 < xmax) v[2] = p[2];
+                    if (x + 3 < xmax) v[3] = p[3];
+                }
+            }
+            r[i] = v;
+        }
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_slab(float* __restrict__ lds, int tid, const f32x4 (&r)[2]) {
+    if (KCONTIG) {
+        const int kq = (tid & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int x = (tid >> 2) + 64 * i;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds[(kq + c) * LDT + x] = r[i][c];
+        }
+    } else {
+        const int xq = (tid & 31) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = (tid >> 5) + 8 * i;
+            *reinterpret_cast<f32x4*>(&lds[k * LDT + xq]) = r[i];
+        }
+    }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
+                                                          int lda, const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, float beta,
+                                                          int tiles_n, int k_per_split, int use_atomic) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDT];  // [buf][A|B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int kbeg = blockIdx.y * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    const int nslab = (kend - kbeg + BK - 1) / BK;
+    if (nslab > 0) {
+        load_slab<A_KCONTIG, VEC>(A, lda, m0, M, kbeg, kend, tid, ra);
+        load_slab<B_KCONTIG, VEC>(B, ldb, n0, N, kbeg, kend, tid, rb);
+        store_slab<A_KCONTIG>(lds[0][0], tid, ra);
+        store_slab<B_KCONTIG>(lds[0][1], tid, rb);
+    }
+    __syncthreads();
+
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nslab) {
+            load_slab<A_KCONTIG, VEC>(A, lda, m0, M, kbeg + (s + 1) * BK, kend, tid, ra);
+            load_slab<B_KCONTIG, VEC>(B, ldb, n0, N, kbeg + (s + 1) * BK, kend, tid, rb);
+        }
+        const float* as = lds[cur][0] + wm * 64 + lr;
+        const float* bs = lds[cur][1] + wn * 64 + lr;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = as[(kk + lh) * LDT];
+            const float a1 = as[(kk + lh) * LDT + 32];
+            const float b0 = bs[(kk + lh) * LDT];
+            const float b1 = bs[(kk + lh) * LDT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < nslab) {
+            store_slab<A_KCONTIG>(lds[cur ^ 1][0], tid, ra);
+            store_slab<B_KCONTIG>(lds[cur ^ 1][1], tid, rb);
+        }
+        __syncthreads();
+    }
+
+    // C/D map of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + lr;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) {
+                    float* c = C + (size_t)m * ldc + n;
+                    if (use_atomic)
+                        atomicAdd(c, acc[i][j][r]);
+                    else
+                        *c = (beta != 0.f) ? acc[i][j][r] + beta * (*c) : acc[i][j][r];
+                }
+            }
+        }
+}
+
+template <bool AK, bool BKc>
+int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float beta,
+           int split_k, hipStream_t st) {
+    const int tm = ds2_cdiv(M, BM), tn = ds2_cdiv(N, BN);
+    if (split_k < 1) split_k = 1;
+    int kper = ds2_cdiv(ds2_cdiv(K, split_k), BK) * BK;
+    if (kper < BK) kper = BK;
+    const int nsplit = ds2_cdiv(K, kper);
+    const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
+    dim3 grid(tm * tn, nsplit), block(256);
+    const int atomic = nsplit > 1 ? 1 : 0;
+    if (vec)
+        hipLaunchKernelGGL((gemm_f32_kernel<AK, BKc, true>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc,
+                           beta, tn, kper, atomic);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<AK, BKc, false>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc,
+                           beta, tn, kper, atomic);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda,
+                            const float* B, int ldb, float* C, int ldc, float beta, int split_k, void* stream) {
+    DS2_CHECK_ARG(M > 0 && N > 0 && K > 0);
+    DS2_CHECK_ARG(A && B && C);
+    DS2_CHECK_ARG(beta == 0.f || beta == 1.f);
+    DS2_CHECK_ARG(split_k <= 1 || beta == 1.f);
+    DS2_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N);
+    hipStream_t st = (hipStream_t)stream;
+    if (!trans_a && !trans_b) launch<true, false>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    else if (!trans_a && trans_b) launch<true, true>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    else if (trans_a && !trans_b) launch<false, false>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    else launch<false, true>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}

@@ -1,0 +1,98 @@
+"""ctypes binding of libds2hip.so (the C ABI declared in include/ds2hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  Importing this module
+without a built libds2hip.so raises; calling an entry point on tensors that are not on a
+ROCm device raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libds2hip.so')
+
+_I = ctypes.c_int
+_F = ctypes.c_float
+_P = ctypes.c_void_p
+_Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); tests/test_abi.py checks this table against include/ds2hip.h
+SIGNATURES = {
+    'ds2_last_error': (ctypes.c_char_p, []),
+    'ds2_version': (_I, []),
+    'ds2_spectrogram_ws_bytes': (_Z, [_I, _I]),
+    'ds2_spectrogram_fwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    'ds2_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _F, _I, _P]),
+    'ds2_transpose_btf_to_bft': (_I, [_P, _I, _I, _I, _P, _P]),
+    'ds2_conv_wt_ws_floats': (_Z, [_I]),
+    'ds2_conv_fwd': (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    'ds2_conv2_dgrad': (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    'ds2_conv_wgrad': (_I, [_I, _P, _P, _I, _I, _P, _P, _P]),
+    'ds2_bn_ws_bytes': (_Z, [_I]),
+    'ds2_bn2d_stats': (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
+    'ds2_bn2d_apply_htanh': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    'ds2_bn2d_htanh_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'ds2_bn1d_stats': (_I, [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
+    'ds2_bn1d_apply': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    'ds2_bn1d_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    'ds2_gru_bidir_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    'ds2_gru_bidir_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'ds2_transpose2d': (_I, [_P, _I, _I, _P, _P]),
+    'ds2_softmax_rows': (_I, [_P, _I, _I, _P, _P]),
+    'ds2_argmax_rows': (_I, [_P, _I, _I, _P, _P]),
+    'ds2_greedy_collapse': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'ds2_ctc_ws_bytes': (_Z, [_I, _I, _I, _I]),
+    'ds2_ctc_loss_grad': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'ds2_sumsq_ws_bytes': (_Z, [_Z]),
+    'ds2_sumsq': (_I, [_P, _Z, _P, _P, _P]),
+    'ds2_clip_sgd_nesterov': (_I, [_P, _P, _P, _Z, _P, _F, _F, _F, _F, _I, _P]),
+    'ds2_add2': (_I, [_P, _P, _Z, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libds2hip.so once; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libds2hip.so is missing at %s -- run `python aes-lac-2018_amd/csrc/build.py` '
+                               '(or __graft_entry__.build()); there is no fallback path' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError('ds2hip entry points take device tensors; got a CPU tensor')
+        if not x.is_contiguous():
+            raise RuntimeError('ds2hip entry points take contiguous tensors')
+        return x.data_ptr()
+    return x
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on the current torch stream; raise on error."""
+    lib = load()
+    rc = getattr(lib, name)(*[_ptr(a) for a in args], stream_ptr())
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, lib.ds2_last_error().decode()))
+
+
+def query(name, *args):
+    """Invoke a size query (no stream, no status)."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,214 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs with torch, launch HIP kernels.
+
+Every function takes/returns ROCm device tensors (fp32 unless noted).  PyTorch is used only as
+the allocator and stream owner; all arithmetic happens inside libds2hip.so.
+"""
+import torch
+
+from . import lib
+
+F_BINS = 161
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _bytes_ws(nbytes, like):
+    return torch.empty((int(nbytes) + 15) // 16 * 2, dtype=torch.float64, device=like.device)
+
+
+def conv_out_frames(t_in):
+    t1 = (t_in + 20 - 11) // 2 + 1
+    return t1, t1 - 10
+
+
+# ----------------------------------------------------------------------------- frontend
+def spectrogram(wav, wav_offsets, t_max, normalize=True, eps=1e-9):
+    """wav: concatenated clips (sum L,), wav_offsets (B+1,) int64 -> (B, t_max, 161)."""
+    bsz = wav_offsets.numel() - 1
+    out = _empty((bsz, t_max, F_BINS), wav)
+    ws = _bytes_ws(lib.query('ds2_spectrogram_ws_bytes', bsz, t_max), wav)
+    lib.call('ds2_spectrogram_fwd', wav, wav_offsets, bsz, t_max, int(normalize), float(eps), out, ws)
+    return out
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm(a, b, trans_a=False, trans_b=False, out=None, beta=0.0, m=None, n=None, k=None, lda=None, ldb=None,
+         ldc=None, split_k=1):
+    """C = op(a) @ op(b) (+ beta*C).  a, b 2-D row-major unless explicit dims/ld are given."""
+    if m is None:
+        m = a.shape[1] if trans_a else a.shape[0]
+    if k is None:
+        k = a.shape[0] if trans_a else a.shape[1]
+    if n is None:
+        n = b.shape[0] if trans_b else b.shape[1]
+    if lda is None:
+        lda = a.shape[-1]
+    if ldb is None:
+        ldb = b.shape[-1]
+    if out is None:
+        out = _empty((m, n), a)
+    if ldc is None:
+        ldc = out.shape[-1]
+    lib.call('ds2_gemm_f32', int(trans_a), int(trans_b), m, n, k, a, lda, b, ldb, out, ldc, float(beta), split_k)
+    return out
+
+
+def gemm_raw(trans_a, trans_b, m, n, k, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, beta=0.0, split_k=1):
+    """Pointer-level GEMM for sub-matrix views (pointers are ints = data_ptr() + byte offsets)."""
+    lib.call('ds2_gemm_f32', int(trans_a), int(trans_b), m, n, k, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, float(beta),
+             split_k)
+
+
+def transpose2d(x, rows, cols, out=None):
+    if out is None:
+        out = _empty((cols, rows), x)
+    lib.call('ds2_transpose2d', x, rows, cols, out)
+    return out
+
+
+def add2(a, b):
+    out = torch.empty_like(a)
+    lib.call('ds2_add2', a, b, a.numel(), out)
+    return out
+
+
+# ----------------------------------------------------------------------------- conv stack
+def transpose_btf(x):
+    bsz, t, f = x.shape
+    out = _empty((bsz, f, t), x)
+    lib.call('ds2_transpose_btf_to_bft', x, bsz, t, f, out)
+    return out
+
+
+def conv_fwd(which, inp, weight, bias, t_in):
+    bsz = inp.shape[0]
+    t1, t2 = conv_out_frames(t_in) if which == 1 else (None, t_in - 10)
+    out = _empty((bsz, 32, 61, t1), inp) if which == 1 else _empty((bsz, 32, 21, t2), inp)
+    ws = _empty((lib.query('ds2_conv_wt_ws_floats', which),), inp)
+    lib.call('ds2_conv_fwd', which, inp, weight, bias, bsz, t_in, out, ws)
+    return out
+
+
+def conv2_dgrad(d_out, weight, t1):
+    bsz = d_out.shape[0]
+    d_in = _empty((bsz, 32, 61, t1), d_out)
+    ws = _empty((lib.query('ds2_conv_wt_ws_floats', 2),), d_out)
+    lib.call('ds2_conv2_dgrad', d_out, weight, bsz, t1, d_in, ws)
+    return d_in
+
+
+def conv_wgrad(which, inp, d_out, t_in, d_weight, d_bias):
+    lib.call('ds2_conv_wgrad', which, inp, d_out, inp.shape[0], t_in, d_weight, d_bias)
+
+
+# ----------------------------------------------------------------------------- batch norm
+def _bn_ws(c, like):
+    return _bytes_ws(lib.query('ds2_bn_ws_bytes', c), like)
+
+
+def bn2d_stats(x, running_mean, running_var, training):
+    bsz, c = x.shape[0], x.shape[1]
+    inner = x.numel() // (bsz * c)
+    mi = _empty((2 * c,), x)
+    lib.call('ds2_bn2d_stats', x, bsz, c, inner, BN_EPS, BN_MOMENTUM, int(not training), running_mean, running_var, mi,
+             _bn_ws(c, x))
+    return mi
+
+
+def bn2d_apply_htanh(x, mi, gamma, beta, layout_tbf):
+    bsz, c, d, t = x.shape
+    y = _empty((t, bsz, c * d), x) if layout_tbf else torch.empty_like(x)
+    lib.call('ds2_bn2d_apply_htanh', x, mi, gamma, beta, bsz, c, d, t, int(layout_tbf), y)
+    return y
+
+
+def bn2d_htanh_bwd(x, dy, mi, gamma, beta, dgamma, dbeta):
+    bsz, c, d, t = x.shape
+    dx = torch.empty_like(x)
+    lib.call('ds2_bn2d_htanh_bwd', x, dy, mi, gamma, beta, bsz, c, d, t, dx, dgamma, dbeta, _bn_ws(c, x))
+    return dx
+
+
+def bn1d_stats(xa, xb, rows, feat, running_mean, running_var, training):
+    mi = _empty((2 * feat,), xa)
+    lib.call('ds2_bn1d_stats', xa, xb, rows, feat, BN_EPS, BN_MOMENTUM, int(not training), running_mean, running_var,
+             mi, _bn_ws(feat, xa))
+    return mi
+
+
+def bn1d_apply(xa, xb, mi, gamma, beta, rows, feat):
+    y = _empty((rows, feat), xa)
+    lib.call('ds2_bn1d_apply', xa, xb, mi, gamma, beta, rows, feat, y)
+    return y
+
+
+def bn1d_bwd(xa, xb, dy, mi, gamma, rows, feat, dgamma, dbeta):
+    dx = _empty((rows, feat), xa)
+    lib.call('ds2_bn1d_bwd', xa, xb, dy, mi, gamma, rows, feat, dx, dgamma, dbeta, _bn_ws(feat, xa))
+    return dx
+
+
+# ----------------------------------------------------------------------------- GRU recurrence
+def gru_bidir_fwd(gates, w_hh, t, bsz, hid):
+    """gates (T,B,2,3H) holds gi on entry, (r,z,n) on exit.  Returns (ghn (T,B,2,H), hout (2,T,B,H))."""
+    ghn = _empty((t, bsz, 2, hid), gates)
+    hout = _empty((2, t, bsz, hid), gates)
+    lib.call('ds2_gru_bidir_fwd', gates, ghn, hout, w_hh, t, bsz, hid)
+    return ghn, hout
+
+
+def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid):
+    ws = torch.zeros((2 * 2 * bsz * hid,), dtype=torch.float32, device=gates.device)
+    lib.call('ds2_gru_bidir_bwd', gates, ghn, hout, d_out, w_hh_t, ws, t, bsz, hid)
+
+
+# ----------------------------------------------------------------------------- head / decode
+def softmax_rows(x, rows, a):
+    y = torch.empty_like(x)
+    lib.call('ds2_softmax_rows', x, rows, a, y)
+    return y
+
+
+def argmax_rows(x, rows, a):
+    idx = _empty((rows,), x, torch.int32)
+    lib.call('ds2_argmax_rows', x, rows, a, idx)
+    return idx
+
+
+def greedy_collapse(best, sizes, blank=0):
+    bsz, t = best.shape
+    ids = torch.zeros((bsz, t), dtype=torch.int32, device=best.device)
+    offs = torch.zeros((bsz, t), dtype=torch.int32, device=best.device)
+    lens = torch.zeros((bsz,), dtype=torch.int32, device=best.device)
+    lib.call('ds2_greedy_collapse', best, sizes, bsz, t, blank, ids, offs, lens)
+    return ids, offs, lens
+
+
+# ----------------------------------------------------------------------------- CTC
+def ctc_loss_grad(acts, labels, label_offsets, label_lens, act_lens, max_label_len):
+    """acts (T,B,A) -> costs (B,), grad (T,B,A); int32 device tensors for the rest."""
+    t, bsz, a = acts.shape
+    costs = _empty((bsz,), acts)
+    grad = torch.empty_like(acts)
+    ws = _bytes_ws(lib.query('ds2_ctc_ws_bytes', t, bsz, a, max_label_len), acts)
+    lib.call('ds2_ctc_loss_grad', acts, labels, label_offsets, label_lens, act_lens, t, bsz, a, max_label_len, costs,
+             grad, ws)
+    return costs, grad
+
+
+# ----------------------------------------------------------------------------- optimiser
+def sumsq(x, out=None):
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float64, device=x.device)
+    ws = _bytes_ws(lib.query('ds2_sumsq_ws_bytes', x.numel()), x)
+    lib.call('ds2_sumsq', x, x.numel(), out, ws)
+    return out
+
+
+def clip_sgd_nesterov(p, g, buf, sumsq_t, grad_scale, max_norm, lr, momentum, first_step):
+    lib.call('ds2_clip_sgd_nesterov', p, g, buf, p.numel(), sumsq_t, float(grad_scale), float(max_norm), float(lr),
+             float(momentum), int(first_step))

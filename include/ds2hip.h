@@ -1,0 +1,185 @@
+/*
+ * ds2hip.h -- C ABI of libds2hip.so: the MI355X (gfx950) DeepSpeech2 hot path.
+ *
+ * The reference (igormq/aes-lac-2018) has no FFI of its own: its hot path bottoms out in
+ * torch.nn modules (cuDNN/ATen), librosa and the warp-ctc binding.  Each entry point below
+ * replaces one of those call sites; the citation gives the reference line it stands in for.
+ * Bindings: aes-lac-2018_amd/ds2hip/lib.py (ctypes); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all tensors are dense fp32 row-major unless stated, int32 for lengths/labels;
+ *   - the caller owns every buffer (inputs, outputs, saved-for-backward tensors, workspaces);
+ *     the library never allocates or frees device memory and keeps no mutable global state;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work;
+ *   - return value 0 = ok, negative = error (DS2_ERR_*); ds2_last_error() returns a
+ *     thread-local message.  No exceptions cross the boundary.
+ *
+ * Shapes: B batch, T_in spectrogram frames, F=161 bins, T1 = (T_in+9)/2+1 frames after conv1,
+ * T = T1-10 frames after conv2, H GRU hidden size, A alphabet size (blank = 0).
+ */
+#ifndef DS2HIP_H
+#define DS2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS2_OK 0
+#define DS2_ERR_ARG (-1)
+#define DS2_ERR_LAUNCH (-2)
+#define DS2_ERR_UNSUPPORTED (-3)
+
+const char* ds2_last_error(void);
+int ds2_version(void);
+
+/* ------------------------------------------------------------------ frontend
+ * Replaces ToSpectrogram.__call__ (librosa branch), codes/transforms.py:94-119, run per
+ * utterance in codes/data.py:61-62, and the zero-padding collate of codes/data.py:132-152.
+ *   wav          concatenated clips, clip b = wav[wav_offsets[b] .. wav_offsets[b+1])
+ *   wav_offsets  (B+1) int64 device
+ *   out          (B, t_max, 161), zero-filled past each clip's 1 + L_b/160 frames
+ *   stats_ws     workspace, >= ds2_spectrogram_ws_bytes(B, t_max) bytes
+ * STFT: reflect-pad 160, frame 320 / hop 160, symmetric Hann, |rFFT|, log1p, then per-clip
+ * (S - mean) / (std_unbiased + eps).
+ */
+size_t ds2_spectrogram_ws_bytes(int B, int t_max);
+int ds2_spectrogram_fwd(const float* wav, const int64_t* wav_offsets, int B, int t_max, int normalize,
+                        float eps, float* out, void* stats_ws, void* stream);
+
+/* ------------------------------------------------------------------ generic fp32 GEMM (MFMA)
+ * C[M,N] = op(A) * op(B) + beta * C, row-major with leading dimensions.  op(A)=A (M x K, lda) or
+ * A^T (A stored K x M); op(B)=B (K x N, ldb) or B^T (B stored N x K).  beta is 0 or 1.
+ * Stands in for the cuBLAS calls behind nn.Linear / nn.GRU's input projection
+ * (codes/model.py:51-52,178-180).  split_k > 1 accumulates partial products with atomics
+ * (requires beta handled by the caller: C must already hold beta*C, pass beta=1).
+ */
+int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
+                 int ldb, float* C, int ldc, float beta, int split_k, void* stream);
+
+/* ------------------------------------------------------------------ conv stack
+ * Replaces nn.Conv2d at codes/model.py:143-144 (cuDNN).  Layouts are NCHW with time innermost:
+ *   conv1: x_t (B,161,T_in) [the transposed input, codes/model.py:184] -> y (B,32,61,T1)
+ *          kernel (32,1,41,11), stride (2,2), padding (0,10)
+ *   conv2: a1 (B,32,61,T1) -> y (B,32,21,T); kernel (32,32,21,11), stride (2,1), no padding
+ * which = 1 or 2.  Weights are passed in the torch layout (Cout,Cin,KF,KT) plus bias (32).
+ * wt_ws: workspace of ds2_conv_wt_ws_floats(which) floats for the re-laid-out filter.
+ */
+int ds2_transpose_btf_to_bft(const float* x, int B, int T, int F, float* x_t, void* stream);
+size_t ds2_conv_wt_ws_floats(int which);
+int ds2_conv_fwd(int which, const float* in, const float* weight, const float* bias, int B, int t_in_frames,
+                 float* out, float* wt_ws, void* stream);
+/* dgrad (conv2 only): d_in (B,32,61,T1) from d_out (B,32,21,T) */
+int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, int T1, float* d_in, float* wt_ws,
+                    void* stream);
+/* wgrad: d_weight (Cout,Cin,KF,KT) and d_bias (32) OVERWRITTEN (d_weight zeroed inside) */
+int ds2_conv_wgrad(int which, const float* in, const float* d_out, int B, int t_in_frames, float* d_weight,
+                   float* d_bias, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm
+ * BatchNorm2d(32)+Hardtanh(0,20) of codes/model.py:143-145 on (B,C,D,T) and the sequence-wise
+ * BatchNorm1d of codes/model.py:27-34,50,59-60,178 on (rows=T*B, F) -- both including padded
+ * frames, eps 1e-5, momentum 0.1, running_var fed the unbiased estimate.
+ *
+ * Training: *_stats computes batch mean / biased var into stat[0:C], stat[C:2C] (=mean, invstd
+ * after finalisation) and updates running_mean/var; *_apply normalises.  Eval: pass
+ * use_running=1 to *_stats to derive mean/invstd from the running buffers instead.
+ * ws: >= ds2_bn_ws_bytes(C) bytes.
+ */
+size_t ds2_bn_ws_bytes(int C);
+/* conv flavour, x (B,C,inner) with inner = D*T */
+int ds2_bn2d_stats(const float* x, int B, int C, int inner, float eps, float momentum, int use_running,
+                   float* running_mean, float* running_var, float* mean_invstd, void* ws, void* stream);
+/* y = hardtanh(bn(x), 0, 20); layout_tbf=0: y (B,C,inner); layout_tbf=1 (conv2 -> GRU input, fuses
+ * codes/model.py:189-192): x (B,C,D,T) -> y (T,B,C*D) */
+int ds2_bn2d_apply_htanh(const float* x, const float* mean_invstd, const float* gamma, const float* beta,
+                         int B, int C, int D, int T, int layout_tbf, float* y, void* stream);
+/* backward of the above: dy (B,C,D,T) [a (T,B,C*D) gradient is first brought back with
+ * ds2_transpose2d(dy, T, B*C*D)] -> dx (B,C,D,T); dgamma,dbeta (C) overwritten */
+int ds2_bn2d_htanh_bwd(const float* x, const float* dy, const float* mean_invstd, const float* gamma,
+                       const float* beta, int B, int C, int D, int T, float* dx, float* dgamma,
+                       float* dbeta, void* ws, void* stream);
+/* sequence flavour.  x = xa (+ xb if xb != NULL): the sum of the two GRU directions
+ * (codes/model.py:64-67) is folded into the BN read.  rows = T*B. */
+int ds2_bn1d_stats(const float* xa, const float* xb, int rows, int F, float eps, float momentum,
+                   int use_running, float* running_mean, float* running_var, float* mean_invstd, void* ws,
+                   void* stream);
+int ds2_bn1d_apply(const float* xa, const float* xb, const float* mean_invstd, const float* gamma,
+                   const float* beta, int rows, int F, float* y, void* stream);
+/* dx (rows,F) = BN backward of dy; x recomputed from xa(+xb).  dgamma, dbeta overwritten. */
+int ds2_bn1d_bwd(const float* xa, const float* xb, const float* dy, const float* mean_invstd,
+                 const float* gamma, int rows, int F, float* dx, float* dgamma, float* dbeta, void* ws,
+                 void* stream);
+
+/* ------------------------------------------------------------------ bidirectional GRU recurrence
+ * Replaces nn.GRU(bias=False, bidirectional=True) (codes/model.py:51-52,62) -- the cuDNN RNN.
+ * The input projection gi = X W_ih^T is a ds2_gemm_f32 call made by the caller into G.
+ *   G     (T,B,2,3H)  in: gi (gate order r,z,n; dir 0 forward, dir 1 reverse)
+ *                     out: the gate activations r,z,n (saved for backward)
+ *   ghn   (T,B,2,H)   out: W_hn h_{t-1} (saved for backward)
+ *   hout  (2,T,B,H)   out: hidden state of each direction at every step; h_0 = 0; the reverse
+ *                     direction runs t = T-1 .. 0 over the PADDED length (no packing, :62)
+ *   w_hh  (2,3H,H)    both directions' recurrent weights, dir-major
+ * The caller sums hout[0]+hout[1] (codes/model.py:64-67) inside the next BN read.
+ */
+int ds2_gru_bidir_fwd(float* G, float* ghn, float* hout, const float* w_hh, int T, int B, int H,
+                      void* stream);
+/* BPTT.  d_out (T,B,H) is the gradient w.r.t. the direction SUM (so it feeds both directions).
+ *   G     in: r,z,n  out: d(gi) = [dr_pre, dz_pre, dn_pre]      (T,B,2,3H)
+ *   ghn   in: W_hn h  out: d(gh_n) = dn_pre * r                  (T,B,2,H)
+ *   w_hh_t (2,H,3H)   transposed recurrent weights (ds2_transpose2d per direction)
+ *   dh_ws  workspace of 2*2*B*H floats
+ */
+int ds2_gru_bidir_bwd(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
+                      float* dh_ws, int T, int B, int H, void* stream);
+int ds2_transpose2d(const float* in, int rows, int cols, float* out, void* stream);
+
+/* ------------------------------------------------------------------ output head helpers
+ * softmax over the last dim of (rows, A) (eval branch, codes/model.py:204-205) and the argmax
+ * of GreedyDecoder.decode (codes/decoder.py:154; ties -> lowest index). */
+int ds2_softmax_rows(const float* x, int rows, int A, float* y, void* stream);
+int ds2_argmax_rows(const float* x, int rows, int A, int32_t* idx, void* stream);
+/* greedy collapse on device: best (B,T) int32 (batch-major), sizes (B) -> out_ids (B,T) and
+ * out_offsets (B,T) compacted per row, out_lens (B)   (codes/decoder.py:123-140) */
+int ds2_greedy_collapse(const int32_t* best, const int32_t* sizes, int B, int T, int blank,
+                        int32_t* out_ids, int32_t* out_offsets, int32_t* out_lens, void* stream);
+
+/* ------------------------------------------------------------------ CTC
+ * Replaces warpctc_pytorch.CTCLoss (train.py:179, codes/engine.py:22, codes/metrics.py:51):
+ * softmax over A inside, blank 0, costs[b] = -log p(labels_b | acts[:act_lens[b], b]),
+ * grad = d(sum_b costs[b]) / d acts (zero for t >= act_lens[b]; zero for an utterance whose
+ * alignment is infeasible, whose cost is +inf).
+ *   acts (T,B,A); labels flat int32 (sum label_lens); label_offsets (B) int32 start of each
+ *   utterance's labels; ws >= ds2_ctc_ws_bytes(T,B,A,max_label_len) bytes
+ */
+size_t ds2_ctc_ws_bytes(int T, int B, int A, int max_label_len);
+int ds2_ctc_loss_grad(const float* acts, const int32_t* labels, const int32_t* label_offsets,
+                      const int32_t* label_lens, const int32_t* act_lens, int T, int B, int A,
+                      int max_label_len, float* costs, float* grad, void* ws, void* stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * clip_grad_norm_(params, max_norm) + SGD(momentum, nesterov) (codes/engine.py:87-90) over ONE
+ * flat fp32 buffer of n elements (the model keeps params / grads / momentum flat).
+ *   ds2_sumsq: partial sums of squares -> out[0] (double) ; ws >= ds2_sumsq_ws_bytes(n)
+ *   ds2_clip_sgd_nesterov: coef = min(1, max_norm / (sqrt(sumsq[0] * norm_scale^2) + 1e-6)) is
+ *   computed ON DEVICE from sumsq (no host sync); g' = g * grad_scale * coef;
+ *   buf = first_step ? g' : momentum*buf + g'; p -= lr * (g' + momentum*buf)
+ * grad_scale lets the data-parallel average (1/world) fold into the update.
+ */
+size_t ds2_sumsq_ws_bytes(size_t n);
+int ds2_sumsq(const float* x, size_t n, double* out, void* ws, void* stream);
+int ds2_clip_sgd_nesterov(float* p, const float* g, float* buf, size_t n, const double* sumsq,
+                          float grad_scale, float max_norm, float lr, float momentum, int first_step,
+                          void* stream);
+
+/* misc elementwise used by the layer glue */
+int ds2_add2(const float* a, const float* b, size_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DS2HIP_H */

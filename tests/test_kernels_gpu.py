@@ -1,0 +1,322 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from ds2hip import ops as _ops
+    return _ops
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize('m,n,k', [(128, 128, 16), (300, 200, 100), (37, 29, 800), (1000, 4800, 672),
+                                   (29, 800, 555), (5, 7, 3), (257, 129, 33)])
+def test_gemm_matches_fp64(ops, ta, tb, m, n, k):
+    rng = np.random.default_rng(m * 7 + n * 3 + k + ta * 2 + tb)
+    a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    out = ops.gemm(_t(a), _t(b), trans_a=bool(ta), trans_b=bool(tb)).cpu().numpy()
+    scale = np.sqrt(k)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6 * scale * 4)
+
+
+def test_gemm_beta_and_splitk(ops):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((5000, 96)).astype(np.float32)      # stored K x M (trans_a)
+    b = rng.standard_normal((5000, 200)).astype(np.float32)
+    c0 = rng.standard_normal((96, 200)).astype(np.float32)
+    ref = a.astype(np.float64).T @ b.astype(np.float64) + c0
+    c = _t(c0.copy())
+    ops.gemm(_t(a), _t(b), trans_a=True, out=c, beta=1.0)
+    np.testing.assert_allclose(c.cpu().numpy(), ref, atol=1e-3)
+    c = _t(c0.copy())
+    ops.gemm(_t(a), _t(b), trans_a=True, out=c, beta=1.0, split_k=4)
+    np.testing.assert_allclose(c.cpu().numpy(), ref, atol=1e-3)
+
+
+def test_gemm_identity_asymmetric(ops):
+    # A = I with an asymmetric B catches a transposed C write
+    b = np.arange(64 * 96, dtype=np.float32).reshape(64, 96)
+    out = ops.gemm(_t(np.eye(64, dtype=np.float32)), _t(b)).cpu().numpy()
+    assert np.array_equal(out, b)
+    out = ops.gemm(_t(b), _t(np.eye(96, dtype=np.float32))).cpu().numpy()
+    assert np.array_equal(out, b)
+
+
+def test_gemm_strided_views(ops):
+    rng = np.random.default_rng(2)
+    big_a = rng.standard_normal((50, 48)).astype(np.float32)   # use columns 8..23 (lda = 48)
+    b = rng.standard_normal((40, 16)).astype(np.float32)
+    ta_, tb_ = _t(big_a), _t(b)
+    out = torch.zeros(50, 40, device=DEV)
+    ops.gemm_raw(0, 1, 50, 40, 16, ta_.data_ptr() + 8 * 4, 48, tb_.data_ptr(), 16, out.data_ptr(), 40)
+    ref = big_a[:, 8:24].astype(np.float64) @ b.astype(np.float64).T
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- misc
+def test_transposes(ops):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3, 77, 161)).astype(np.float32)
+    assert np.array_equal(ops.transpose_btf(_t(x)).cpu().numpy(), x.transpose(0, 2, 1))
+    y = rng.standard_normal((45, 1000)).astype(np.float32)
+    assert np.array_equal(ops.transpose2d(_t(y), 45, 1000).cpu().numpy(), y.T)
+
+
+def test_softmax_argmax_collapse(ops):
+    from oracle import host
+    rng = np.random.default_rng(4)
+    for a in (29, 43):
+        x = rng.standard_normal((301, a)).astype(np.float32)
+        x[5, 3] = x[5, 9] = 10.0                         # a tie -> lowest index
+        ref = torch.softmax(torch.from_numpy(x), -1).numpy()
+        np.testing.assert_allclose(ops.softmax_rows(_t(x), 301, a).cpu().numpy(), ref, atol=1e-6)
+        assert np.array_equal(ops.argmax_rows(_t(x), 301, a).cpu().numpy(), x.argmax(1))
+    labels = ['_'] + [chr(65 + i) for i in range(28)]
+    probs = rng.random((4, 150, 29)).astype(np.float32)
+    probs[:, :, 0] += 0.4                                # plenty of blanks
+    probs[1, 10:20, 5] = 9.0                             # a run of repeats
+    sizes = np.asarray([150, 97, 1, 0], dtype=np.int32)
+    best = ops.argmax_rows(_t(probs.reshape(-1, 29)), 600, 29).reshape(4, 150)
+    ids, offs, lens = ops.greedy_collapse(best, _t(sizes))
+    strings, offsets = host.greedy_decode(probs, sizes, labels)
+    for b in range(4):
+        n = int(lens[b])
+        got = ''.join(labels[i] for i in ids[b, :n].cpu().numpy())
+        assert got == strings[b]
+        assert np.array_equal(offs[b, :n].cpu().numpy(), offsets[b])
+
+
+# ------------------------------------------------------------------------------------------- frontend
+def test_spectrogram_matches_oracle(ops):
+    from oracle import spectrogram as ospec
+    rng = np.random.default_rng(5)
+    lens = [16000, 37923, 24000, 161, 16159]
+    wavs = [np.clip(0.1 * rng.standard_normal(n), -1, 1).astype(np.float32) for n in lens]
+    ref, pct = ospec.batch_log_spectrogram(wavs)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    out = ops.spectrogram(_t(np.concatenate(wavs)), _t(offs), ref.shape[1]).cpu().numpy()
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-4)
+    # un-normalised log-magnitudes too
+    raw = ops.spectrogram(_t(wavs[0]), _t(np.asarray([0, lens[0]], np.int64)), 101, normalize=False).cpu().numpy()[0]
+    np.testing.assert_allclose(raw, np.log1p(ospec.stft_magnitude(wavs[0])), atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------- conv
+def _conv_ref(which, x, w, b):
+    if which == 1:
+        return F.conv2d(x, w, b, stride=(2, 2), padding=(0, 10))
+    return F.conv2d(x, w, b, stride=(2, 1))
+
+
+@pytest.mark.parametrize('which,bsz,t_in', [(1, 2, 121), (1, 3, 64), (2, 2, 66), (2, 1, 43), (1, 1, 301)])
+def test_conv_fwd_bwd(ops, which, bsz, t_in):
+    rng = np.random.default_rng(10 * which + bsz)
+    cin, fin, kf = (1, 161, 41) if which == 1 else (32, 61, 21)
+    x = torch.from_numpy(rng.standard_normal((bsz, cin, fin, t_in)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((32, cin, kf, 11)) / np.sqrt(cin * kf * 11)).astype(np.float32))
+    w.requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal(32).astype(np.float32)).requires_grad_(True)
+    ref = _conv_ref(which, x, w, b)
+    dy = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+    ref.backward(dy)
+    out = ops.conv_fwd(which, x.detach().to(DEV).contiguous().view(bsz, cin * fin, t_in) if which == 1
+                       else x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV), t_in)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-5)
+    dw = torch.empty_like(w, device=DEV)
+    db = torch.empty(32, device=DEV)
+    ops.conv_wgrad(which, x.detach().to(DEV), dy.to(DEV), t_in, dw, db)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=2e-4)
+    if which == 2:
+        dx = ops.conv2_dgrad(dy.to(DEV), w.detach().to(DEV), t_in)
+        np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------- BN
+def test_bn2d_train_eval_and_backward(ops):
+    rng = np.random.default_rng(20)
+    bsz, c, d, t = 3, 32, 21, 57
+    x = torch.from_numpy((3 * rng.standard_normal((bsz, c, d, t)) + 5).astype(np.float32)).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.uniform(-1, 6, c).astype(np.float32)))
+    rm, rv = bn.running_mean.clone().to(DEV), bn.running_var.clone().to(DEV)
+    y = F.hardtanh(bn(x), 0, 20)
+    dy = torch.from_numpy(rng.standard_normal((bsz, c, d, t)).astype(np.float32))
+    y.backward(dy)
+    g, be = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    xd = x.detach().to(DEV)
+    mi = ops.bn2d_stats(xd, rm, rv, training=True)
+    out = ops.bn2d_apply_htanh(xd, mi, g, be, layout_tbf=False)
+    np.testing.assert_allclose(out.cpu().numpy(), y.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5)
+    out_t = ops.bn2d_apply_htanh(xd, mi, g, be, layout_tbf=True)
+    ref_t = y.detach().reshape(bsz, c * d, t).permute(2, 0, 1).contiguous().numpy()
+    np.testing.assert_allclose(out_t.cpu().numpy(), ref_t, atol=2e-5)
+    dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    dx = ops.bn2d_htanh_bwd(xd, dy.to(DEV), mi, g, be, dg, db)
+    np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), atol=2e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), bn.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bn.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+    bn.eval()
+    with torch.no_grad():
+        y_eval = F.hardtanh(bn(x.detach()), 0, 20)
+    mi_e = ops.bn2d_stats(xd, rm, rv, training=False)
+    out_e = ops.bn2d_apply_htanh(xd, mi_e, g, be, layout_tbf=False)
+    np.testing.assert_allclose(out_e.cpu().numpy(), y_eval.numpy(), atol=2e-5)
+
+
+def test_bn1d_with_direction_sum(ops):
+    rng = np.random.default_rng(21)
+    rows, feat = 530, 800
+    xa = torch.from_numpy(rng.standard_normal((rows, feat)).astype(np.float32)).requires_grad_(True)
+    xb = torch.from_numpy((2 * rng.standard_normal((rows, feat)) + 1).astype(np.float32))
+    bn = torch.nn.BatchNorm1d(feat)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, feat).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.uniform(-1, 1, feat).astype(np.float32)))
+    rm, rv = bn.running_mean.clone().to(DEV), bn.running_var.clone().to(DEV)
+    y = bn(xa + xb)
+    dy = torch.from_numpy(rng.standard_normal((rows, feat)).astype(np.float32))
+    y.backward(dy)
+    g, be = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    a_, b_ = xa.detach().to(DEV), xb.to(DEV)
+    mi = ops.bn1d_stats(a_, b_, rows, feat, rm, rv, training=True)
+    out = ops.bn1d_apply(a_, b_, mi, g, be, rows, feat)
+    np.testing.assert_allclose(out.cpu().numpy(), y.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5)
+    dg, db = torch.empty(feat, device=DEV), torch.empty(feat, device=DEV)
+    dx = ops.bn1d_bwd(a_, b_, dy.to(DEV), mi, g, rows, feat, dg, db)
+    np.testing.assert_allclose(dx.cpu().numpy(), xa.grad.numpy(), atol=2e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), bn.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bn.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # single-input form
+    mi1 = ops.bn1d_stats(a_, None, rows, feat, None, None, training=True)
+    ref1 = F.batch_norm(xa.detach(), None, None, bn.weight.detach(), bn.bias.detach(), True)
+    np.testing.assert_allclose(ops.bn1d_apply(a_, None, mi1, g, be, rows, feat).cpu().numpy(), ref1.numpy(), atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------- GRU
+@pytest.mark.parametrize('t,bsz,n_in,hid', [(9, 3, 24, 32), (6, 10, 40, 800), (5, 20, 16, 64), (4, 40, 16, 72),
+                                            (3, 64, 8, 800), (1, 2, 8, 16)])
+def test_gru_recurrence_fwd_bwd(ops, t, bsz, n_in, hid):
+    torch.manual_seed(t * 100 + bsz)
+    gru = torch.nn.GRU(n_in, hid, bidirectional=True, bias=False)
+    x = torch.randn(t, bsz, n_in, requires_grad=True)
+    y, _ = gru(x)
+    ysum = y[:, :, :hid] + y[:, :, hid:]
+    dy = torch.randn(t, bsz, hid)
+    ysum.backward(dy)
+    w_ih = torch.cat([gru.weight_ih_l0, gru.weight_ih_l0_reverse], 0).detach().to(DEV).contiguous()   # (6H, In)
+    w_hh = torch.stack([gru.weight_hh_l0, gru.weight_hh_l0_reverse], 0).detach().to(DEV).contiguous()  # (2,3H,H)
+    xd = x.detach().to(DEV)
+    gates = ops.gemm(xd.view(t * bsz, n_in), w_ih, trans_b=True).view(t, bsz, 2, 3 * hid)
+    ghn, hout = ops.gru_bidir_fwd(gates, w_hh, t, bsz, hid)
+    got = (hout[0] + hout[1]).cpu().numpy()
+    np.testing.assert_allclose(got, ysum.detach().numpy(), atol=3e-5)
+    np.testing.assert_allclose(hout[0].cpu().numpy(), y[:, :, :hid].detach().numpy(), atol=3e-5)
+    # saved tensors against the explicit restatement (forward direction)
+    from oracle.model import gru_direction_explicit
+    sv = gru_direction_explicit(x.detach(), gru.weight_ih_l0.detach(), gru.weight_hh_l0.detach())
+    np.testing.assert_allclose(gates[:, :, 0, :hid].cpu().numpy(), sv['r'].numpy(), atol=3e-5)
+    np.testing.assert_allclose(gates[:, :, 0, 2 * hid:].cpu().numpy(), sv['n'].numpy(), atol=3e-5)
+    np.testing.assert_allclose(ghn[:, :, 0].cpu().numpy(), sv['ghn'].numpy(), atol=3e-5)
+    # backward
+    w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
+    ops.gru_bidir_bwd(gates, ghn, hout, dy.to(DEV), w_hh_t, t, bsz, hid)
+    dgi = gates.view(t * bsz, 6 * hid)
+    dx = ops.gemm(dgi, w_ih)                                    # (TB, In)
+    np.testing.assert_allclose(dx.view(t, bsz, n_in).cpu().numpy(), x.grad.numpy(), atol=5e-5)
+    dw_ih = ops.gemm(dgi, xd.view(t * bsz, n_in), trans_a=True)  # (6H, In)
+    ref_dw_ih = torch.cat([gru.weight_ih_l0.grad, gru.weight_ih_l0_reverse.grad], 0).numpy()
+    np.testing.assert_allclose(dw_ih.cpu().numpy(), ref_dw_ih, rtol=1e-4, atol=1e-4)
+    if t > 1:
+        # dW_hh (forward direction) = dGH[1:]^T h[:-1]
+        dgh = torch.cat([gates[1:, :, 0, :2 * hid], ghn[1:, :, 0, :]], -1).reshape((t - 1) * bsz, 3 * hid).contiguous()
+        hprev = hout[0, :-1].reshape((t - 1) * bsz, hid).contiguous()
+        dw_hh = ops.gemm(dgh, hprev, trans_a=True)
+        np.testing.assert_allclose(dw_hh.cpu().numpy(), gru.weight_hh_l0.grad.numpy(), rtol=1e-4, atol=1e-4)
+        dgh_r = torch.cat([gates[:-1, :, 1, :2 * hid], ghn[:-1, :, 1, :]], -1).reshape((t - 1) * bsz, 3 * hid)
+        hnext = hout[1, 1:].reshape((t - 1) * bsz, hid).contiguous()
+        dw_hh_r = ops.gemm(dgh_r.contiguous(), hnext, trans_a=True)
+        np.testing.assert_allclose(dw_hh_r.cpu().numpy(), gru.weight_hh_l0_reverse.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- CTC
+def _ctc_case(ops, t_max, bsz, nalpha, label_lens, act_lens, seed, repeat_first=True):
+    from oracle import ctc as octc
+    rng = np.random.default_rng(seed)
+    acts = (2 * rng.standard_normal((t_max, bsz, nalpha))).astype(np.float32)
+    labels = rng.integers(1, nalpha, size=int(sum(label_lens))).astype(np.int32)
+    if repeat_first and label_lens[0] > 1:
+        labels[1] = labels[0]
+    offs = np.concatenate([[0], np.cumsum(label_lens)[:-1]]).astype(np.int32)
+    costs, grad = ops.ctc_loss_grad(_t(acts), _t(labels), _t(offs), _t(np.asarray(label_lens, np.int32)),
+                                    _t(np.asarray(act_lens, np.int32)), int(max(label_lens)))
+    ref_costs, ref_grad = octc.ctc_loss_and_grad(acts, labels, act_lens, label_lens)
+    return costs.cpu().numpy(), grad.cpu().numpy(), ref_costs, ref_grad
+
+
+@pytest.mark.parametrize('nalpha', [29, 43])
+def test_ctc_ragged(ops, nalpha):
+    costs, grad, rc, rg = _ctc_case(ops, 60, 5, nalpha, [7, 0, 12, 3, 20], [60, 31, 44, 9, 41], seed=nalpha)
+    np.testing.assert_allclose(costs, rc, rtol=1e-4)
+    np.testing.assert_allclose(grad, rg, atol=2e-5)
+    assert np.all(grad[31:, 1] == 0)
+
+
+def test_ctc_infeasible_and_long(ops):
+    # utterance 1 needs 3 labels + 2 repeats > 4 frames: cost +inf, zero gradient
+    from oracle import ctc as octc
+    acts = np.random.default_rng(7).standard_normal((8, 2, 5)).astype(np.float32)
+    labels = np.asarray([1, 2, 3, 3, 3], np.int32)
+    costs, grad = ops.ctc_loss_grad(_t(acts), _t(labels), _t(np.asarray([0, 2], np.int32)),
+                                    _t(np.asarray([2, 3], np.int32)), _t(np.asarray([8, 4], np.int32)), 3)
+    rc, rg = octc.ctc_loss_and_grad(acts, labels, [8, 4], [2, 3])
+    assert np.isinf(costs.cpu().numpy()[1]) and np.isinf(rc[1])
+    np.testing.assert_allclose(costs.cpu().numpy()[0], rc[0], rtol=1e-5)
+    assert np.all(grad.cpu().numpy()[:, 1] == 0)
+    np.testing.assert_allclose(grad.cpu().numpy()[:, 0], rg[:, 0], atol=2e-5)
+    # long utterance: T = 746, L = 200 (S = 401 states, two states per thread)
+    costs, grad, rc, rg = _ctc_case(ops, 746, 2, 29, [200, 150], [746, 700], seed=9)
+    np.testing.assert_allclose(costs, rc, rtol=1e-4)
+    np.testing.assert_allclose(grad, rg, atol=5e-5)
+
+
+# ------------------------------------------------------------------------------------------- optimiser
+def test_clip_sgd_matches_torch(ops):
+    torch.manual_seed(0)
+    n = 100003
+    p = torch.nn.Parameter(torch.randn(n))
+    opt = torch.optim.SGD([p], lr=3e-4, momentum=0.9, nesterov=True)
+    n_pad = (n + 3) // 4 * 4
+    pd = torch.zeros(n_pad, device=DEV); pd[:n] = p.detach().to(DEV)
+    buf = torch.zeros(n_pad, device=DEV)
+    for step, scale in enumerate((10.0, 0.01, 50.0)):
+        g = torch.randn(n) * scale
+        p.grad = g.clone()
+        total = torch.nn.utils.clip_grad_norm_([p], 400.0)
+        opt.step()
+        gd = torch.zeros(n_pad, device=DEV); gd[:n] = g.to(DEV)
+        ss = ops.sumsq(gd)
+        assert abs(float(ss.item()) ** 0.5 - float(total)) < 1e-3 * float(total)
+        ops.clip_sgd_nesterov(pd, gd, buf, ss, 1.0, 400.0, 3e-4, 0.9, step == 0)
+        np.testing.assert_allclose(pd[:n].cpu().numpy(), p.detach().numpy(), atol=2e-6)
