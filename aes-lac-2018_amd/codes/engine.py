@@ -1,0 +1,241 @@
+"""Training / evaluation step (reference ``codes/engine.py``), without ignite.
+
+``create_trainer(model, optimizer, criterion, device, **kwargs)`` keeps the reference's signature and
+step semantics (``codes/engine.py:35-100``):
+    out = model(inputs); loss = criterion(out^T, targets, (pct*T).int(), sizes) / B; +-inf -> 0;
+    zero_grad; backward; clip_grad_norm_(max_norm); optimizer.step(); synchronize; return loss.item()
+but the whole step is HIP kernels on flat buffers: one fused forward/backward pass (no autograd graph),
+the CTC gradient already scaled by 1/B, one sum-of-squares pass and one fused clip + Nesterov-SGD pass that
+derives the clip coefficient on the device.  With ``torch.distributed`` initialised (one process per GPU,
+RCCL over xGMI) the flat gradient is sum-all-reduced in per-layer buckets on a side stream while backward
+is still running, and the 1/world average folds into the update kernel; BatchNorm statistics stay
+per-replica, as under the reference's DDP (``train.py:172-175``).
+
+The optimizer object is the reference's ``torch.optim.SGD`` (built from the JSON config): learning rate,
+momentum and the LR scheduler keep working through ``optimizer.param_groups``; its momentum buffers are
+views of the trainer's flat momentum buffer so ``optimizer.state_dict()`` checkpoints as before.  Any
+other optimizer falls back to ``loss.backward()`` through the model's autograd node + ``optimizer.step()``.
+"""
+import logging
+import time
+
+import torch
+import torch.distributed as dist
+
+from ds2hip import ops
+
+from .ctc import ctc_costs_and_grad
+
+LOG = logging.getLogger('aes-lac-2018')
+
+
+def sanitize_inputs(out_seq_length, input_percentages):
+    """(input_percentages * T).int(): float32 multiply then truncation -- codes/engine.py:12-16."""
+    return (input_percentages.to('cpu', torch.float32) * out_seq_length).int()
+
+
+class Trainer(object):
+    def __init__(self, model, optimizer, criterion=None, device='cuda', max_norm=400, skip_n=0, frontend=None,
+                 overlap_allreduce=True):
+        self.model, self.optimizer, self.criterion = model, optimizer, criterion
+        self.device = torch.device(device)
+        self.max_norm = max_norm
+        self.skip_n = skip_n
+        self.frontend = frontend
+        self.iteration = 0
+        self.data_time = 0.0
+        self.last_grad_norm = None
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.overlap = overlap_allreduce and self.world > 1
+        self._comm_stream = None
+        self._buf = None
+        self._first = True
+        self._sumsq = None
+        model._ensure_flat()
+        if self.world > 1:                       # DDP construction: rank 0's parameters and buffers win
+            dist.broadcast(model._flat_p, 0)
+            for b in model.buffers():
+                dist.broadcast(b, 0)
+        self._fused = self._fused_ok()
+        if self._fused:
+            self._bind_momentum()
+
+    # ---------------------------------------------------------------- optimizer plumbing
+    def _fused_ok(self):
+        opt = self.optimizer
+        if not isinstance(opt, torch.optim.SGD) or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        trainable = all(p.requires_grad for p in self.model._plist)
+        return (g.get('nesterov', False) and g.get('momentum', 0) > 0 and g.get('dampening', 0) == 0 and
+                g.get('weight_decay', 0) == 0 and trainable)
+
+    def _bind_momentum(self):
+        """Flat momentum buffer; the torch optimizer's per-parameter state entries are views of it."""
+        m = self.model
+        self._buf = torch.zeros_like(m._flat_p)
+        loaded = False
+        for p, o in zip(m._plist, m._offsets):
+            view = self._buf[o:o + p.numel()].view(p.shape)
+            st = self.optimizer.state[p]
+            old = st.get('momentum_buffer', None)
+            if old is not None:                  # resumed optimizer state (train.py:142-150)
+                view.copy_(old)
+                loaded = True
+            st['momentum_buffer'] = view
+        self._first = not loaded
+
+    # ---------------------------------------------------------------- one optimisation step
+    def update(self, batch):
+        if self.skip_n > 0:                      # codes/engine.py:46-49 (resume mid-epoch)
+            self.skip_n -= 1
+            return 'Skipped'
+        model = self.model
+        model.train()
+        t0 = time.time()
+        inputs, targets, input_percentages, target_sizes = batch
+        if self.frontend is not None and isinstance(inputs, (list, tuple)):
+            inputs, input_percentages = self.frontend(inputs)          # raw clips -> device spectrograms
+        inputs = inputs.to(self.device, non_blocking=True)
+        self.data_time = time.time() - t0
+        bsz = inputs.shape[0]
+
+        if not self._fused:
+            return self._update_autograd(inputs, targets, input_percentages, target_sizes)
+
+        def loss_fn(acts):
+            out_sizes = sanitize_inputs(acts.shape[0], input_percentages)
+            costs, d_acts = ctc_costs_and_grad(acts, targets, out_sizes, target_sizes, grad_scale=1.0 / bsz)
+            return costs, d_acts
+
+        hook = self._bucket_hook() if self.overlap else None
+        costs, _ = self._forward_backward(inputs, loss_fn, hook)
+        gflat = model.flat_grad()
+        if self.world > 1:
+            if self.overlap:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+            else:
+                dist.all_reduce(gflat)
+        scale = 1.0 / self.world
+        self._sumsq = ops.sumsq(gflat, self._sumsq)
+        g = self.optimizer.param_groups[0]
+        ops.clip_sgd_nesterov(model._flat_p, gflat, self._buf, self._sumsq, scale, self.max_norm, g['lr'],
+                              g['momentum'], self._first)
+        self._first = False
+        loss = costs.sum() / bsz
+        torch.cuda.synchronize()                                          # codes/engine.py:92
+        self.iteration += 1
+        loss_v = float(loss.item())
+        self.last_grad_norm = float(self._sumsq.item()) ** 0.5 * scale
+        if loss_v in (float('inf'), float('-inf')):
+            LOG.warning('WARNING: received an inf loss, setting loss value to 0')   # codes/engine.py:27-30
+            loss_v = 0.0
+        return loss_v
+
+    def _forward_backward(self, inputs, loss_fn, hook):
+        m = self.model
+        m._ensure_flat()
+        gflat = m.flat_grad()
+        acts, sv = m._forward_impl(inputs.contiguous().float(), training=True, need_grad=True)
+        costs, d_acts = loss_fn(acts)
+        m._backward_impl(sv, d_acts, gflat, grad_ready=hook)
+        return costs, acts
+
+    def _bucket_hook(self):
+        """all-reduce each finished slice of the flat gradient on a side stream (overlaps with backward)."""
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        comm = self._comm_stream
+        gflat = self.model.flat_grad()
+
+        def ready(lo, hi):
+            comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm):
+                dist.all_reduce(gflat[lo:hi])
+        return ready
+
+    def _update_autograd(self, inputs, targets, input_percentages, target_sizes):
+        """Reference-shaped step through autograd, for optimizers the fused kernel does not cover."""
+        out = self.model(inputs)                                        # (B,T,A)
+        out_sizes = sanitize_inputs(out.shape[1], input_percentages)
+        loss = self.criterion(out.transpose(0, 1), targets, out_sizes, target_sizes) / inputs.shape[0]
+        loss = loss.sum()
+        if float(loss.item()) in (float('inf'), float('-inf')):
+            LOG.warning('WARNING: received an inf loss, setting loss value to 0')
+            self.optimizer.zero_grad()
+            return 0.0
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.world > 1:
+            for p in self.model.parameters():
+                if p.grad is not None:
+                    dist.all_reduce(p.grad)
+                    p.grad.div_(self.world)
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
+        self.optimizer.step()
+        torch.cuda.synchronize()
+        self.iteration += 1
+        return float(loss.item())
+
+    def run(self, loader, num_epochs=1, on_iteration=None, on_epoch=None):
+        for epoch in range(num_epochs):
+            for i, batch in enumerate(loader):
+                loss = self.update(batch)
+                if on_iteration is not None:
+                    on_iteration(self, epoch, i, loss)
+            if on_epoch is not None:
+                on_epoch(self, epoch)
+
+
+class Evaluator(object):
+    """Inference step + metrics (reference ``codes/engine.py:103-130``, ``codes/metrics.py``)."""
+
+    def __init__(self, model, decoder=None, device='cuda'):
+        self.model, self.decoder, self.device = model, decoder, torch.device(device)
+
+    def inference(self, batch):
+        self.model.eval()
+        with torch.no_grad():
+            inputs, targets, input_percentages, target_sizes = batch
+            out = self.model(inputs.to(self.device))                     # (B,T,A) probabilities
+            out_sizes = sanitize_inputs(out.shape[1], input_percentages)
+            return out, targets.to('cpu'), out_sizes, target_sizes.to('cpu')
+
+    def run(self, loader):
+        """Returns dict(ctcloss, wer, cer) with the training-time metric definitions:
+        ctcloss = sum of CTC costs on the eval-mode outputs (probabilities, soft-maxed again inside the loss,
+        ``codes/metrics.py:49-51``) / utterances; wer / cer = mean over utterances of distance / reference
+        length, x100 (``codes/metrics.py:114-132,143-162``)."""
+        tot_loss, n_utt, wer_sum, cer_sum = 0.0, 0, 0.0, 0.0
+        for batch in loader:
+            out, targets, out_sizes, target_sizes = self.inference(batch)
+            costs, _ = ctc_costs_and_grad(out.transpose(0, 1).contiguous(), targets, out_sizes, target_sizes)
+            tot_loss += float(costs.sum().item())
+            n_utt += out.shape[0]
+            if self.decoder is not None:
+                hyps, _ = self.decoder.decode(out, out_sizes)
+                off = 0
+                for i in range(out.shape[0]):
+                    n = int(target_sizes[i])
+                    ref = self.decoder.convert_to_strings([targets[off:off + n]])[0][0]
+                    off += n
+                    hyp = hyps[i][0]
+                    nw, nc = len(ref.split()), len(ref)
+                    w, c = self.decoder.wer(hyp, ref), self.decoder.cer(hyp, ref)
+                    wer_sum += w / nw if nw else w
+                    cer_sum += c / nc if nc else c
+        n = max(n_utt, 1)
+        return {'ctcloss': tot_loss / n, 'wer': 100.0 * wer_sum / n, 'cer': 100.0 * cer_sum / n}
+
+
+def create_trainer(model, optimizer, criterion, device, **kwargs):
+    """Same call as the reference (``train.py:199-200``): kwargs carry max_norm, skip_n, task_weights..."""
+    if len(kwargs.get('task_weights', [1])) > 1:
+        raise NotImplementedError('multi-task training is out of scope (SURVEY.md section 2)')
+    crit = criterion[0] if isinstance(criterion, (list, tuple)) else criterion
+    return Trainer(model, optimizer, crit, device, max_norm=kwargs.get('max_norm', 400),
+                   skip_n=kwargs.get('skip_n', 0), frontend=kwargs.get('frontend', None))
+
+
+def create_evaluator(model, metrics=None, device='cuda', decoder=None):
+    return Evaluator(model, decoder, device)

@@ -289,8 +289,22 @@ class DeepSpeech(nn.Module):
         return self._flat_p[off:off + 2 * n].view(2 * p_fwd.shape[0], p_fwd.shape[1])
 
     # ------------------------------------------------------------------ backward
-    def _backward_impl(self, sv, d_acts, gflat):
-        """d_acts (T,B,A) -> gradients of every parameter written into ``gflat`` (same layout as the flat params)."""
+    def _span(self, first, last):
+        """[lo, hi) of the flat buffer covering parameters first..last (inclusive, flat order)."""
+        lo = hi = None
+        for q, o in zip(self._plist, self._offsets):
+            if q is first:
+                lo = o
+            if q is last:
+                hi = o + (q.numel() + 3) // 4 * 4
+        return lo, hi
+
+    def _backward_impl(self, sv, d_acts, gflat, grad_ready=None):
+        """d_acts (T,B,A) -> gradients of every parameter written into ``gflat`` (same layout as the flat params).
+
+        ``grad_ready(lo, hi)`` is called as soon as the slice [lo, hi) of ``gflat`` is final (head, then each
+        GRU layer top-down, then the conv stack) so a data-parallel trainer can start its all-reduce early.
+        """
         hid, ncls = self._rnn_hidden_size, self._num_classes
         t, bsz, t1, t_in = sv['t'], sv['bsz'], sv['t1'], sv['t_in']
         rows = t * bsz
@@ -302,6 +316,8 @@ class DeepSpeech(nn.Module):
         last = sv['layers'][-1]['hout']
         dy = ops.bn1d_bwd(last[0], last[1], dxf, sv['mi_fc'], head[0].weight, rows, hid, gv(head[0].weight),
                           gv(head[0].bias))
+        if grad_ready is not None:
+            grad_ready(*self._span(head[0].weight, head[1].weight))
         nl = len(sv['layers'])
         f4 = 4
         for li in range(nl - 1, -1, -1):
@@ -341,6 +357,9 @@ class DeepSpeech(nn.Module):
                                   gv(bn.bias))
             else:
                 dy = dxin
+            if grad_ready is not None:
+                first = layer.batch_norm.module.weight if layer.batch_norm is not None else r.weight_ih_l0
+                grad_ready(*self._span(first, r.weight_hh_l0_reverse))
             rec.clear()
         c = self.conv
         d_a2 = ops.transpose2d(dy, t, bsz * self._rnn_input_size).view(bsz, 32, 21, t)   # (T,B,672) -> (B,32,21,T)
@@ -349,6 +368,8 @@ class DeepSpeech(nn.Module):
         d_a1 = ops.conv2_dgrad(d_y2, c[3].weight, t1)
         d_y1 = ops.bn2d_htanh_bwd(sv['y1'], d_a1, sv['mi1'], c[1].weight, c[1].bias, gv(c[1].weight), gv(c[1].bias))
         ops.conv_wgrad(1, sv['xt'], d_y1, t_in, gv(c[0].weight), gv(c[0].bias))
+        if grad_ready is not None:
+            grad_ready(*self._span(c[0].weight, c[4].bias))
 
     def _pair_view(self, gflat, p_fwd, p_rev):
         n = p_fwd.numel()

@@ -1,0 +1,79 @@
+"""Log-spectrogram frontend on the GPU (reference ``codes/transforms.py:26-127``, ``ToSpectrogram``).
+
+The reference runs ``librosa.stft`` per utterance on CPU DataLoader workers (``codes/data.py:61-62``,
+``codes/transforms.py:94-119``).  Here the same arithmetic -- centre reflect-pad 160, 320-sample frames
+every 160, symmetric Hann (``librosa_compat=True`` forces ``periodic=False``, ``:52-53``), |rFFT|, log1p,
+per-utterance (S - mean) / (std_unbiased + eps) -- is one HIP kernel pair (csrc/spectrogram.hip) that
+processes a whole padded minibatch after collate: ``BatchSpectrogram``.  ``ToSpectrogram`` keeps the
+reference's constructor and per-utterance ``__call__`` for drop-in use.
+"""
+import torch
+
+from ds2hip import ops
+
+FRAME, HOP, NBINS = 320, 160, 161
+
+
+class ToSpectrogram(object):
+    def __init__(self, frame_length=320, hop=160, fft_size=None, pad_end=0, normalize=True,
+                 window=torch.hann_window, window_params=None, librosa_compat=False, eps=1e-9, device='cuda'):
+        fft_size = fft_size or frame_length
+        hop = hop if hop is not None else frame_length // 2
+        window_params = dict(window_params or {})
+        if librosa_compat:
+            window_params.setdefault('periodic', False)
+        ok = (frame_length == FRAME and hop == HOP and fft_size == FRAME and pad_end == 0 and librosa_compat and
+              window is torch.hann_window and window_params == {'periodic': False})
+        if not ok:
+            raise NotImplementedError('the HIP frontend implements the configuration the reference trains with: '
+                                      'frame 320, hop 160, symmetric Hann, librosa_compat=True '
+                                      '(codes/utils/training_utils.py:19-23)')
+        self.frame_length, self.hop, self.fft_size = frame_length, hop, fft_size
+        self.normalize, self.pad_end, self.eps = normalize, pad_end, eps
+        self.window_params, self.librosa_compat = window_params, librosa_compat
+        self.device = device
+
+    def __call__(self, x):
+        """x: 1-D float tensor of samples -> (T_in, 161) on x's device (a CPU input makes a GPU round trip)."""
+        assert x.dim() == 1 and isinstance(x, torch.Tensor)
+        src = x.device
+        wav = x.to(self.device, torch.float32).contiguous()
+        assert wav.numel() > FRAME // 2, 'reflect padding needs more than 160 samples'
+        offs = torch.tensor([0, wav.numel()], dtype=torch.int64, device=wav.device)
+        out = ops.spectrogram(wav, offs, 1 + wav.numel() // HOP, self.normalize, self.eps)[0]
+        return out.to(src)
+
+    def __repr__(self):
+        return ('{}(frame_length={}, hop={}, fft_size={}, pad_end={}, normalize={},librosa_compat={})').format(
+            self.__class__.__name__, self.frame_length, self.hop, self.fft_size, self.pad_end, self.normalize,
+            self.librosa_compat)
+
+
+class BatchSpectrogram(object):
+    """Frontend + collate for a minibatch of raw clips, entirely on the device.
+
+    ``__call__(wavs)`` with ``wavs`` a list of 1-D tensors (or (flat, offsets)) returns
+    ``inputs (B,T_max,161)`` and ``input_percentages (B)`` float32 exactly as
+    ``AudioDataLoader._collate_fn`` would have (``codes/data.py:132-152``): zero padding past each
+    clip's frames, percentage = T_i / float(T_max) stored as float32.
+    """
+
+    def __init__(self, normalize=True, eps=1e-9, device='cuda'):
+        self.normalize, self.eps, self.device = normalize, eps, device
+
+    def __call__(self, wavs, offsets=None):
+        if offsets is None:
+            lens = [int(w.numel()) for w in wavs]
+            flat = torch.cat([w.reshape(-1).to(self.device, torch.float32) for w in wavs])
+        else:
+            flat = wavs.to(self.device, torch.float32).contiguous()
+            lens = [int(offsets[i + 1] - offsets[i]) for i in range(len(offsets) - 1)]
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        frames = [1 + n // HOP for n in lens]
+        t_max = max(frames)
+        offs_d = torch.tensor(offs, dtype=torch.int64, device=flat.device)
+        inputs = ops.spectrogram(flat, offs_d, t_max, self.normalize, self.eps)
+        pct = torch.tensor([f / float(t_max) for f in frames], dtype=torch.float32)
+        return inputs, pct

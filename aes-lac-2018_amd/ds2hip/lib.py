@@ -43,7 +43,7 @@ SIGNATURES = {
     'ds2_argmax_rows': (_I, [_P, _I, _I, _P, _P]),
     'ds2_greedy_collapse': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'ds2_ctc_ws_bytes': (_Z, [_I, _I, _I, _I]),
-    'ds2_ctc_loss_grad': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'ds2_ctc_loss_grad': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     'ds2_sumsq_ws_bytes': (_Z, [_Z]),
     'ds2_sumsq': (_I, [_P, _Z, _P, _P, _P]),
     'ds2_clip_sgd_nesterov': (_I, [_P, _P, _P, _Z, _P, _F, _F, _F, _F, _I, _P]),

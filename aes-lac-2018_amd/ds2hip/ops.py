@@ -189,14 +189,14 @@ def greedy_collapse(best, sizes, blank=0):
 
 
 # ----------------------------------------------------------------------------- CTC
-def ctc_loss_grad(acts, labels, label_offsets, label_lens, act_lens, max_label_len):
+def ctc_loss_grad(acts, labels, label_offsets, label_lens, act_lens, max_label_len, grad_scale=1.0):
     """acts (T,B,A) -> costs (B,), grad (T,B,A); int32 device tensors for the rest."""
     t, bsz, a = acts.shape
     costs = _empty((bsz,), acts)
     grad = torch.empty_like(acts)
     ws = _bytes_ws(lib.query('ds2_ctc_ws_bytes', t, bsz, a, max_label_len), acts)
-    lib.call('ds2_ctc_loss_grad', acts, labels, label_offsets, label_lens, act_lens, t, bsz, a, max_label_len, costs,
-             grad, ws)
+    lib.call('ds2_ctc_loss_grad', acts, labels, label_offsets, label_lens, act_lens, t, bsz, a, max_label_len,
+             float(grad_scale), costs, grad, ws)
     return costs, grad
 
 

@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""Train-throughput benchmark of the MI355X DeepSpeech2 hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full training pass over one minibatch of synthetic 16 kHz clips already resident in HBM:
+GPU log-spectrogram frontend -> conv/BiGRU/FC forward -> CTC -> backward -> (RCCL gradient all-reduce)
+-> clip + Nesterov SGD -> synchronize (the reference's codes/engine.py:45-94).  Workload at N=1:
+BASELINE configs[1] (scripts/librispeech-from_scratch.json): the default 5xBiGRU-800 model, A=29, batch
+10, clip durations uniform on [1 s, 15 s] (numpy default_rng(42)), length-sorted bins of 10 like
+BucketingSampler, labels 14 chars/s.  N>1: each rank takes every N-th bin (DistributedBucketingSampler
+rule, codes/sampler.py:119-125), per-GPU batch stays 10 -> weak scaling; value = frames of all ranks /
+max-over-ranks time.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'aes-lac-2018_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+TRAIN_FLOP_PER_OUT_STEP = 261.94e6  # 3 x 87.31 MFLOP per output step per utterance
+HOP = 160
+NUM_BINS = 24
+
+
+def synth_bins(batch_size, num_bins, seed=42, nalpha=29):
+    """SURVEY.md 8(d) synthetic corpus: returns a list of bins [(wavs list, labels, label_lens)]."""
+    rng = np.random.default_rng(seed)
+    n = batch_size * num_bins
+    dur = np.sort(rng.uniform(1.0, 15.0, size=n))
+    bins = []
+    for i in range(num_bins):
+        wavs, labels, lens = [], [], []
+        for d in dur[i * batch_size:(i + 1) * batch_size]:
+            nsamp = int(round(d * 16000))
+            wavs.append(np.clip(0.1 * rng.standard_normal(nsamp), -1.0, 1.0).astype(np.float32))
+            ll = max(1, int(round(14.0 * d)))
+            labels.append(rng.integers(1, nalpha, size=ll).astype(np.int32))
+            lens.append(ll)
+        bins.append((wavs, np.concatenate(labels), np.asarray(lens, np.int32)))
+    order = np.random.default_rng(seed + 1).permutation(num_bins)   # epoch-2-style shuffled bins
+    return [bins[i] for i in order]
+
+
+def frames_of(bin_):
+    return sum(1 + len(w) // HOP for w in bin_[0])
+
+
+def out_steps_of(bin_):
+    t_in = max(1 + len(w) // HOP for w in bin_[0])
+    return ((t_in + 9) // 2 - 9) * len(bin_[0])      # padded output steps actually computed
+
+
+def cpu_baseline(bins, budget_s=25.0):
+    """The oracle (stock PyTorch CPU ops, numerically the reference) timed on the host cores: one bounded
+    training step (frontend -> fwd -> CTC -> bwd -> clip -> SGD) on the shortest bin(s)."""
+    import torch.nn.functional as F
+    from oracle import spectrogram as ospec
+    from oracle.model import OracleDeepSpeech
+    torch.manual_seed(0)
+    model = OracleDeepSpeech()
+    opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
+    model.train()
+    order = sorted(range(len(bins)), key=lambda i: frames_of(bins[i]))
+    frames, secs, used = 0, 0.0, []
+    for idx in order[:3]:
+        wavs, labels, lens = bins[idx]
+        t0 = time.time()
+        x, pct = ospec.batch_log_spectrogram(wavs)
+        logits = model(torch.from_numpy(x))
+        out_sizes = (torch.from_numpy(pct) * logits.shape[1]).int()
+        loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), torch.from_numpy(labels).long(), out_sizes.long(),
+                          torch.from_numpy(lens).long(), blank=0, reduction='sum') / len(wavs)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 400)
+        opt.step()
+        dt = time.time() - t0
+        if used or len(order) == 1:            # the first step is the warm-up unless it is all we can afford
+            frames += frames_of(bins[idx])
+            secs += dt
+        used.append(idx)
+        if secs + dt > budget_s and frames > 0:
+            break
+        if dt > budget_s:                       # even the warm-up blew the budget: count it
+            frames, secs = frames_of(bins[idx]), dt
+            break
+    return {'value': round(frames / secs, 1), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle (torch CPU conv/BN/GRU/Linear + F.ctc_loss + clip + SGD) full training step on the '
+                      '%d shortest bins of the same workload (B=10; first step = warm-up, untimed), %d frames in %.1f s'
+                      % (len(used), frames, secs)}
+
+
+def gru_step_roofline(model, bsz, t):
+    """Live HIP-event timing of the dominant kernel: the backward GRU time-step (one launch per step)."""
+    from ds2hip import ops
+    hid = model._rnn_hidden_size
+    dev = model._flat_p.device
+    r = model.rnns[1].rnn
+    w_hh = model._pair(r.weight_hh_l0, r.weight_hh_l0_reverse).view(2, 3 * hid, hid)
+    w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
+    gates = 0.1 * torch.randn(t, bsz, 2, 3 * hid, device=dev)
+    res = {}
+    for name in ('fwd', 'bwd'):
+        times = []
+        for _ in range(3):
+            g = gates.clone()
+            ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
+            if name == 'bwd':
+                d_out = 0.01 * torch.randn(t, bsz, hid, device=dev)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if name == 'fwd':
+                g2 = gates.clone()
+                e0.record()
+                ops.gru_bidir_fwd(g2, w_hh, t, bsz, hid)
+                e1.record()
+            else:
+                e0.record()
+                ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
+                e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e-3 / t)
+        res[name] = float(np.median(times))
+    k = {'fwd': hid, 'bwd': 3 * hid}
+    n = {'fwd': 3 * hid, 'bwd': hid}
+    out = {}
+    for name in ('fwd', 'bwd'):
+        flop = 2.0 * 2 * bsz * k[name] * n[name]                      # both directions, one launch
+        out[name] = (flop / res[name] / 1e12, res[name])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=48)
+    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--batch-size', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs an MI355X: the product path has no CPU fallback')
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://')
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    from codes.engine import Trainer
+    from codes.model import DeepSpeech
+    from codes.transforms import BatchSpectrogram
+
+    bsz = args.batch_size
+    bins = synth_bins(bsz, NUM_BINS * world)
+    mine = bins[rank::world]                                             # every world-th bin, starting from rank
+    dev = torch.device('cuda', local)
+    resident = []
+    for wavs, labels, lens in mine:                                       # inputs resident in HBM before timing
+        flat = torch.from_numpy(np.concatenate(wavs)).to(dev)
+        offs = np.concatenate([[0], np.cumsum([len(w) for w in wavs])]).astype(np.int64)
+        resident.append((flat, offs, torch.from_numpy(labels), torch.from_numpy(lens)))
+
+    torch.manual_seed(42)
+    model = DeepSpeech().to(dev)                                          # 5 x BiGRU-800, A = 29, random init
+    opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
+    trainer = Trainer(model, opt, device=dev, max_norm=400)
+    front = BatchSpectrogram(device=dev)
+
+    def step(i):
+        flat, offs, labels, lens = resident[i % len(resident)]
+        inputs, pct = front(flat, offs)
+        return trainer.update((inputs, labels, pct, lens))
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(args.warmup, args.warmup + args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    idxs = [i % len(mine) for i in range(args.warmup, args.warmup + args.steps)]
+    frames = float(sum(frames_of(mine[i]) for i in idxs))
+    osteps = float(sum(out_steps_of(mine[i]) for i in idxs))
+    if world > 1:
+        t = torch.tensor([dt, frames, osteps], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, frames, osteps = float(tmax[0]), float(t[1]), float(t[2])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = frames / dt
+    step_tflops = osteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12 / world    # per GPU, padded steps included
+    t_mid = 400
+    roof = gru_step_roofline(model, bsz, t_mid)
+    ach, dur = roof['bwd']
+    result = {
+        'metric': 'train frames/sec, DeepSpeech2 5xBiGRU-800',
+        'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: librispeech-from_scratch.json, 5xBiGRU-800 A=29, batch %d per GPU, '
+                               '16 kHz clips uniform 1-15 s in length-sorted bins, full train step incl. GPU STFT '
+                               'frontend, CTC, clip+SGD' % bsz,
+                   'batch_per_gpu': bsz, 'global_batch': bsz * world, 'parallelism': 'dp%d' % world,
+                   'last_loss': round(float(loss), 4)},
+        'roofline': {'bound': 'mfma', 'kernel': 'gru_bwd_step_kernel (one launch per time step, both directions)',
+                     'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None,
+                     'avg_launch_us': round(dur * 1e6, 3),
+                     'fwd_step_tflops': round(roof['fwd'][0], 3), 'fwd_step_us': round(roof['fwd'][1] * 1e6, 3),
+                     'flop_per_launch': 2.0 * 2 * bsz * 2400 * 800,
+                     'whole_step_tflops_per_gpu': round(step_tflops, 3),
+                     'whole_step_frac_of_f32_mfma_peak': round(step_tflops / PEAK_F32_MFMA_TFLOPS, 5)},
+    }
+    if not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(bins)
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

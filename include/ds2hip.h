@@ -151,15 +151,17 @@ int ds2_greedy_collapse(const int32_t* best, const int32_t* sizes, int B, int T,
 /* ------------------------------------------------------------------ CTC
  * Replaces warpctc_pytorch.CTCLoss (train.py:179, codes/engine.py:22, codes/metrics.py:51):
  * softmax over A inside, blank 0, costs[b] = -log p(labels_b | acts[:act_lens[b], b]),
- * grad = d(sum_b costs[b]) / d acts (zero for t >= act_lens[b]; zero for an utterance whose
- * alignment is infeasible, whose cost is +inf).
+ * grad = grad_scale * d(sum_b costs[b]) / d acts (zero for t >= act_lens[b]; zero for an utterance
+ * whose alignment is infeasible, whose cost is +inf).  grad_scale carries the 1/B of
+ * codes/engine.py:23,80 so no separate scaling pass is needed.
  *   acts (T,B,A); labels flat int32 (sum label_lens); label_offsets (B) int32 start of each
  *   utterance's labels; ws >= ds2_ctc_ws_bytes(T,B,A,max_label_len) bytes
  */
 size_t ds2_ctc_ws_bytes(int T, int B, int A, int max_label_len);
 int ds2_ctc_loss_grad(const float* acts, const int32_t* labels, const int32_t* label_offsets,
                       const int32_t* label_lens, const int32_t* act_lens, int T, int B, int A,
-                      int max_label_len, float* costs, float* grad, void* ws, void* stream);
+                      int max_label_len, float grad_scale, float* costs, float* grad, void* ws,
+                      void* stream);
 
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_(params, max_norm) + SGD(momentum, nesterov) (codes/engine.py:87-90) over ONE

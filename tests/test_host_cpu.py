@@ -1,0 +1,133 @@
+"""CPU-side checks: C-ABI surface, parameter naming/initialisation/flat layout, host helpers."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import host
+from oracle.model import OracleDeepSpeech
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, 'include', 'ds2hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\n\s*(?:const\s+char\*|int|size_t)\s+(ds2_\w+)\s*\(([^;]*?)\)\s*;', text):
+        args = [a.strip() for a in m.group(2).replace('\n', ' ').split(',')]
+        out[m.group(1)] = [] if args == ['void'] else args
+    return out
+
+
+def test_library_exports_every_declared_symbol():
+    from ds2hip import lib
+    decl = _header_functions()
+    assert len(decl) >= 25
+    assert set(decl) == set(lib.SIGNATURES), set(decl) ^ set(lib.SIGNATURES)
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    for name, args in decl.items():
+        assert hasattr(handle, name), name
+        want = len(lib.SIGNATURES[name][1])
+        assert len(args) == want, (name, args)
+        for a, ct in zip(args, lib.SIGNATURES[name][1]):
+            is_ptr = '*' in a
+            assert is_ptr == (ct is ctypes.c_void_p), (name, a)
+            if not is_ptr:
+                kind = {'int': ctypes.c_int, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t}[a.split()[0]]
+                assert ct is kind, (name, a)
+    assert lib.query('ds2_version') >= 100
+    assert lib.query('ds2_bn_ws_bytes', 32) > 0
+
+
+def test_missing_device_tensor_fails_loudly():
+    from ds2hip import ops
+    with pytest.raises(RuntimeError):
+        ops.softmax_rows(torch.zeros(4, 29), 4, 29)            # CPU tensor: no fallback path
+    from codes.model import DeepSpeech
+    with pytest.raises(RuntimeError):
+        DeepSpeech(rnn_hidden_size=32, num_rnn_layers=1)(torch.zeros(1, 64, 161))
+
+
+def test_state_dict_names_shapes_and_same_seed_init():
+    from codes.model import DeepSpeech
+    torch.manual_seed(7)
+    ours = DeepSpeech(rnn_hidden_size=64, num_rnn_layers=3)
+    torch.manual_seed(7)
+    ref = OracleDeepSpeech(rnn_hidden_size=64, num_rnn_layers=3)    # stock torch modules, reference order
+    sd_o, sd_r = ours.state_dict(), ref.state_dict()
+    assert list(sd_o.keys()) == list(sd_r.keys())
+    for k in sd_r:
+        assert sd_o[k].shape == sd_r[k].shape and sd_o[k].dtype == sd_r[k].dtype, k
+        assert torch.equal(sd_o[k], sd_r[k]), 'same-seed initialisation differs at ' + k
+    assert sum(p.numel() for p in DeepSpeech().parameters()) == 38067968
+
+
+def test_constructor_surface():
+    from codes.model import DeepSpeech
+    m = DeepSpeech(rnn_type='gru', num_classes=43, rnn_hidden_size=32, num_rnn_layers=2, context=20)
+    assert m.fc[0].module[1].weight.shape == (43, 32)
+    with pytest.raises(NotImplementedError):
+        DeepSpeech(bidirectional=False)
+    with pytest.raises(NotImplementedError):
+        DeepSpeech(rnn_type='lstm')
+
+
+def test_flat_parameter_views():
+    from codes.model import DeepSpeech
+    m = DeepSpeech(rnn_hidden_size=32, num_rnn_layers=2)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    m.flatten_parameters()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    r = m.rnns[1].rnn
+    assert r.weight_ih_l0_reverse.data_ptr() == r.weight_ih_l0.data_ptr() + 4 * r.weight_ih_l0.numel()
+    assert r.weight_hh_l0_reverse.data_ptr() == r.weight_hh_l0.data_ptr() + 4 * r.weight_hh_l0.numel()
+    base = m._flat_p.data_ptr()
+    for p, o in zip(m._plist, m._offsets):
+        assert p.data_ptr() == base + 4 * o and o % 4 == 0
+    sd = {k: torch.randn_like(v) if v.dtype.is_floating_point else v for k, v in before.items()}
+    m.load_state_dict(sd)                      # in-place copy keeps the views
+    m._ensure_flat()
+    assert m._flat_p.data_ptr() == base
+    assert torch.equal(m.conv[3].weight, sd['conv.3.weight'])
+    lo, hi = m._span(m.rnns[0].rnn.weight_ih_l0, m.rnns[0].rnn.weight_hh_l0_reverse)
+    assert hi - lo == 2 * (96 * 672 + 96 * 32)
+
+
+def test_host_helpers_match_oracle():
+    from codes.data import collate
+    from codes.engine import sanitize_inputs
+    from codes.preprocessing import OrderedLabelEncoder
+    a, b = torch.ones(3, 4), 2 * torch.ones(5, 4)
+    x, tg, pct, ts = collate([(a, [1, 2]), (b, [3])])
+    ox, otg, opct, ots = host.collate([(a.numpy(), [1, 2]), (b.numpy(), [3])])
+    assert np.array_equal(x.numpy(), ox) and np.array_equal(tg.numpy(), otg)
+    assert np.array_equal(pct.numpy(), opct) and np.array_equal(ts.numpy(), ots)
+    assert tg.dtype == torch.int32 and ts.dtype == torch.int32 and pct.dtype == torch.float32
+    for t_i, t_max in ((101, 1501), (1501, 1501), (747, 1501), (233, 301), (1000, 1500), (333, 999)):
+        t_out = (t_max + 9) // 2 - 9
+        p = torch.tensor([t_i / float(t_max)], dtype=torch.float32)
+        assert sanitize_inputs(t_out, p).numpy()[0] == host.out_sizes(p.numpy(), t_out)[0]
+    enc = OrderedLabelEncoder().fit(list('_ CAB'))
+    assert list(enc.classes_) == ['_', ' ', 'C', 'A', 'B']
+    assert enc.transform(list('CAB')).tolist() == [2, 3, 4]
+    assert ''.join(enc.inverse_transform([2, 3, 4])) == 'CAB'
+    with pytest.raises(ValueError):
+        enc.transform(['Z'])
+
+
+def test_decoder_distances_match_oracle():
+    from codes.decoder import GreedyDecoder
+    dec = GreedyDecoder(['_', ' ', 'A', 'B', 'C'])
+    pairs = [('A B', 'AB'), ('ABC', 'ACB'), ('THE CAT', 'THE CAT SAT'), ('', 'A'), ('A  B C', 'B C')]
+    for h, r in pairs:
+        assert dec.cer(h, r) == host.cer_distance(h, r)
+        assert dec.wer(h, r) == host.wer_distance(h, r)
+    tgt = dec.convert_to_strings([torch.tensor([2, 2, 0, 3])])
+    assert tgt == [['AAB']]                                   # no repetition removal for targets
+    got = dec.convert_to_strings([torch.tensor([2, 2, 0, 3])], remove_repetitions=True, return_offsets=True)
+    assert got[0] == [['AB']] and got[1][0][0].tolist() == [0, 3]

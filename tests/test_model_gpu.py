@@ -1,0 +1,200 @@
+"""End-to-end parity of the HIP model / trainer against the reference's golden outputs and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import host  # noqa: E402
+from oracle.model import OracleDeepSpeech, conv_out_time, seeded_state_dict  # noqa: E402
+from tests.golden.make_golden import seeded_inputs, seeded_labels  # noqa: E402
+
+LABELS = ['_', ' ', "'"] + [chr(65 + i) for i in range(26)]
+
+
+def _build(kwargs):
+    from codes.model import DeepSpeech
+    shapes = OracleDeepSpeech(**kwargs)
+    model = DeepSpeech(**kwargs)
+    assert list(model.state_dict().keys()) == list(shapes.state_dict().keys())
+    model.load_state_dict(seeded_state_dict(shapes, 1234))
+    return model.to('cuda')
+
+
+def _case(golden_dir, name, kwargs, bsz, t_in, lengths, label_lens, full):
+    from codes.ctc import CTCLoss
+    from codes.decoder import GreedyDecoder
+    g = np.load(os.path.join(golden_dir, name))
+    model = _build(kwargs)
+    x = torch.from_numpy(seeded_inputs(77, bsz, t_in, lengths=lengths)).to('cuda')
+    labels = torch.from_numpy(seeded_labels(78, label_lens, 29))
+    model.train()
+    logits = model(x)                                            # autograd path
+    assert tuple(logits.shape) == (bsz, conv_out_time(t_in), 29)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g['logits'], rtol=0, atol=1e-3)
+    pct = torch.from_numpy(g['pct'])
+    out_sizes = (pct * logits.shape[1]).int()
+    assert np.array_equal(out_sizes.numpy(), g['out_sizes'])
+    loss = CTCLoss()(logits.transpose(0, 1), labels, out_sizes, torch.tensor(label_lens, dtype=torch.int32))
+    assert tuple(loss.shape) == (1,)
+    ref_loss = float(g['loss_sum'])
+    assert abs(float(loss.item()) - ref_loss) <= 1e-4 * abs(ref_loss)
+    (loss / bsz).sum().backward()
+    for k, p in model.named_parameters():
+        gn = float(np.sqrt((p.grad.cpu().numpy().astype(np.float64) ** 2).sum()))
+        if k in ('conv.0.bias', 'conv.3.bias'):
+            # a bias in front of a BatchNorm has an exactly-zero gradient; both sides hold only round-off
+            assert gn < 1e-3 and float(g['gnorm_' + k]) < 1e-3, k
+            continue
+        assert abs(gn - float(g['gnorm_' + k])) <= 2e-3 * float(g['gnorm_' + k]) + 1e-6, k
+        if full:
+            ref = g['grad_' + k]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max() + 1e-7,
+                                       err_msg=k)
+        else:
+            flat = p.grad.cpu().numpy().reshape(-1)
+            stride = max(1, flat.shape[0] // 1024)
+            ref = g['gsample_' + k]
+            np.testing.assert_allclose(flat[::stride][:1024], ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max() + 1e-7,
+                                       err_msg=k)
+    for k, v in model.state_dict().items():
+        if 'running' in k:
+            np.testing.assert_allclose(v.cpu().numpy(), g['buf_' + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        probs = model(x)
+    np.testing.assert_allclose(probs.cpu().numpy(), g['probs'], rtol=0, atol=1e-3)
+    # greedy strings: bit-identical to the oracle's decode of the REFERENCE probabilities
+    dec = GreedyDecoder(LABELS)
+    strings, offsets = dec.decode(probs, out_sizes)
+    want, want_off = host.greedy_decode(g['probs'], g['out_sizes'], LABELS)
+    assert [s[0] for s in strings] == want
+    for o, w in zip(offsets, want_off):
+        assert np.array_equal(o[0].numpy(), w)
+    return model
+
+
+def test_tiny_model_against_reference_golden(golden_dir):
+    _case(golden_dir, 'ref_tiny.npz', dict(rnn_hidden_size=32, num_rnn_layers=2), 3, 121, [121, 97, 64], [9, 6, 4],
+          full=True)
+
+
+def test_full_model_against_reference_golden(golden_dir):
+    _case(golden_dir, 'ref_full.npz', dict(), 2, 301, [301, 233], [30, 21], full=False)
+
+
+def test_tiny_intermediates_localise_errors(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ref_tiny.npz'))
+    model = _build(dict(rnn_hidden_size=32, num_rnn_layers=2))
+    x = torch.from_numpy(seeded_inputs(77, 3, 121, lengths=[121, 97, 64])).to('cuda')
+    model.train()
+    model._ensure_flat()
+    acts, sv = model._forward_impl(x, training=True, need_grad=True)
+    np.testing.assert_allclose(sv['a1'].cpu().numpy(), g['inter_conv1'], atol=1e-4)
+    for li in (0, 1):
+        h = sv['layers'][li]['hout']
+        np.testing.assert_allclose((h[0] + h[1]).cpu().numpy(), g['inter_rnn%d' % li], atol=1e-4)
+    x0 = sv['layers'][0]['xin']                                   # (T,B,672) = conv2 output re-laid-out
+    ref = torch.from_numpy(g['inter_conv2'])
+    b, c, d, t = ref.shape
+    np.testing.assert_allclose(x0.cpu().numpy(), ref.reshape(b, c * d, t).permute(2, 0, 1).numpy(), atol=1e-4)
+
+
+def test_trainer_steps_match_oracle_sgd():
+    from codes.engine import Trainer
+    kwargs = dict(rnn_hidden_size=64, num_rnn_layers=3, num_classes=29)
+    oracle = OracleDeepSpeech(**kwargs)
+    oracle.load_state_dict(seeded_state_dict(oracle, 99))
+    model = _build(kwargs)
+    model.load_state_dict(seeded_state_dict(oracle, 99))
+    model.to('cuda')
+    opt_o = torch.optim.SGD(oracle.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
+    trainer = Trainer(model, opt, device='cuda', max_norm=5.0)           # small max_norm: the clip engages
+    rng = np.random.default_rng(3)
+    for step in range(3):
+        t_in = 90 + 10 * step
+        lengths = [t_in, t_in - 17, t_in - 40, 51]
+        x = torch.from_numpy(seeded_inputs(100 + step, 4, t_in, lengths=lengths))
+        label_lens = [6, 4, 3, 2]
+        labels = torch.from_numpy(rng.integers(1, 29, size=sum(label_lens)).astype(np.int32))
+        pct = torch.tensor([n / float(t_in) for n in lengths], dtype=torch.float32)
+        sizes = torch.tensor(label_lens, dtype=torch.int32)
+        oracle.train()
+        logits = oracle(x)
+        out_sizes = (pct * logits.shape[1]).int()
+        loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), labels.long(), out_sizes.long(), sizes.long(),
+                          blank=0, reduction='sum') / 4
+        opt_o.zero_grad()
+        loss.backward()
+        total = torch.nn.utils.clip_grad_norm_(oracle.parameters(), 5.0)
+        opt_o.step()
+        got = trainer.update((x, labels, pct, sizes))
+        assert abs(got - float(loss.item())) <= 2e-4 * abs(float(loss.item()))
+        assert abs(trainer.last_grad_norm - float(total)) <= 5e-3 * float(total)
+        for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), atol=5e-5, err_msg='%s step %d' % (k, step))
+    # the torch optimizer's state is a view of the trainer's flat momentum buffer
+    p0 = next(model.parameters())
+    assert opt.state[p0]['momentum_buffer'].data_ptr() == trainer._buf.data_ptr()
+
+
+def test_frontend_to_strings_pipeline():
+    """raw audio -> GPU spectrogram -> model(eval) -> greedy strings == the same through the oracle."""
+    from codes.decoder import GreedyDecoder
+    from codes.transforms import BatchSpectrogram, ToSpectrogram
+    from oracle import spectrogram as ospec
+    rng = np.random.default_rng(8)
+    wavs = [np.clip(0.1 * rng.standard_normal(n), -1, 1).astype(np.float32) for n in (16000, 20480, 17777)]
+    inputs, pct = BatchSpectrogram()([torch.from_numpy(w) for w in wavs])
+    ref_in, ref_pct = ospec.batch_log_spectrogram(wavs)
+    np.testing.assert_allclose(inputs.cpu().numpy(), ref_in, atol=2e-4)
+    assert np.array_equal(pct.numpy(), ref_pct)
+    one = ToSpectrogram(librosa_compat=True)(torch.from_numpy(wavs[0]))
+    assert one.device.type == 'cpu'
+    np.testing.assert_allclose(one.numpy(), ospec.log_spectrogram(wavs[0]), atol=2e-4)
+    kwargs = dict(rnn_hidden_size=64, num_rnn_layers=2)
+    oracle = OracleDeepSpeech(**kwargs)
+    oracle.load_state_dict(seeded_state_dict(oracle, 5, scale=3.0))
+    model = _build(kwargs)
+    model.load_state_dict(seeded_state_dict(oracle, 5, scale=3.0))
+    model.eval()
+    oracle.eval()
+    with torch.no_grad():
+        probs = model(inputs)
+        ref_probs = oracle(torch.from_numpy(ref_in))
+    np.testing.assert_allclose(probs.cpu().numpy(), ref_probs.numpy(), atol=1e-3)
+    sizes = host.out_sizes(ref_pct, probs.shape[1])
+    strings, _ = GreedyDecoder(LABELS).decode(probs, torch.from_numpy(sizes))
+    want, _ = host.greedy_decode(ref_probs.numpy(), sizes, LABELS)
+    assert [s[0] for s in strings] == want
+
+
+def test_full_size_step_properties():
+    """B=10 x 15 s (T_in=1501 -> T=746) on the real 5xBiGRU-800: shapes, finiteness, loss decreases."""
+    from codes.engine import Trainer
+    from codes.model import DeepSpeech
+    torch.manual_seed(0)
+    model = DeepSpeech().to('cuda')
+    opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
+    trainer = Trainer(model, opt, device='cuda', max_norm=400)
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.standard_normal((10, 1501, 161)).astype(np.float32))
+    label_lens = [int(v) for v in rng.integers(100, 210, size=10)]
+    labels = torch.from_numpy(rng.integers(1, 29, size=sum(label_lens)).astype(np.int32))
+    pct = torch.ones(10)
+    sizes = torch.tensor(label_lens, dtype=torch.int32)
+    losses = [trainer.update((x, labels, pct, sizes)) for _ in range(4)]
+    assert all(np.isfinite(v) and v > 0 for v in losses)
+    assert losses[-1] < losses[0]
+    assert np.isfinite(trainer.last_grad_norm)
+    for p in model.parameters():
+        assert torch.isfinite(p).all()
+    model.eval()
+    with torch.no_grad():
+        probs = model(x.to('cuda'))
+    assert tuple(probs.shape) == (10, 746, 29)
+    np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
