@@ -124,6 +124,7 @@ class Trainer(object):
         self._first = False
         loss = costs.sum() / bsz
         torch.cuda.synchronize()                                          # codes/engine.py:92
+        ops.check_async_errors()
         self.iteration += 1
         loss_v = float(loss.item())
         self.last_grad_norm = float(self._sumsq.item()) ** 0.5 * scale

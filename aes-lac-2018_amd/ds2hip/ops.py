@@ -3,6 +3,8 @@
 Every function takes/returns ROCm device tensors (fp32 unless noted).  PyTorch is used only as
 the allocator and stream owner; all arithmetic happens inside libds2hip.so.
 """
+import os
+
 import torch
 
 from . import lib
@@ -153,17 +155,54 @@ def bn1d_bwd(xa, xb, dy, mi, gamma, rows, feat, dgamma, dbeta):
 
 
 # ----------------------------------------------------------------------------- GRU recurrence
+GRU_MODE = os.environ.get('DS2_GRU_MODE', 'auto')     # 'auto' | 'persistent' | 'step'
+_sync_ws = {}
+
+
+def _gru_sync_ws(dev):
+    """Per-device arrival counters + timeout flag of the persistent recurrence (caller-owned, reused)."""
+    key = (dev.type, dev.index)
+    if key not in _sync_ws:
+        n = (lib.query('ds2_gru_sync_ws_bytes') + 3) // 4
+        _sync_ws[key] = torch.zeros(n, dtype=torch.int32, device=dev)
+    return _sync_ws[key]
+
+
+def _use_persistent(bsz, hid):
+    if GRU_MODE == 'step':
+        return False
+    ok = bool(lib.query('ds2_gru_persistent_supported', bsz, hid))
+    if GRU_MODE == 'persistent' and not ok:
+        raise RuntimeError('persistent GRU kernel does not support B=%d H=%d' % (bsz, hid))
+    return ok
+
+
+def check_async_errors():
+    """Raise if a persistent kernel's bounded spin timed out (call after a device synchronize)."""
+    for ws in _sync_ws.values():
+        if int(ws[-1].item()) != 0:
+            ws.zero_()
+            raise RuntimeError('ds2hip: persistent GRU kernel timed out waiting for a workgroup hand-off')
+
+
 def gru_bidir_fwd(gates, w_hh, t, bsz, hid):
     """gates (T,B,2,3H) holds gi on entry, (r,z,n) on exit.  Returns (ghn (T,B,2,H), hout (2,T,B,H))."""
     ghn = _empty((t, bsz, 2, hid), gates)
     hout = _empty((2, t, bsz, hid), gates)
-    lib.call('ds2_gru_bidir_fwd', gates, ghn, hout, w_hh, t, bsz, hid)
+    if _use_persistent(bsz, hid):
+        lib.call('ds2_gru_bidir_fwd_persistent', gates, ghn, hout, w_hh, _gru_sync_ws(gates.device), t, bsz, hid)
+    else:
+        lib.call('ds2_gru_bidir_fwd', gates, ghn, hout, w_hh, t, bsz, hid)
     return ghn, hout
 
 
 def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid):
-    ws = torch.zeros((2 * 2 * bsz * hid,), dtype=torch.float32, device=gates.device)
-    lib.call('ds2_gru_bidir_bwd', gates, ghn, hout, d_out, w_hh_t, ws, t, bsz, hid)
+    if _use_persistent(bsz, hid):
+        lib.call('ds2_gru_bidir_bwd_persistent', gates, ghn, hout, d_out, w_hh_t, _gru_sync_ws(gates.device), t, bsz,
+                 hid)
+    else:
+        ws = torch.zeros((2 * 2 * bsz * hid,), dtype=torch.float32, device=gates.device)
+        lib.call('ds2_gru_bidir_bwd', gates, ghn, hout, d_out, w_hh_t, ws, t, bsz, hid)
 
 
 # ----------------------------------------------------------------------------- head / decode

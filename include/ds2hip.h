@@ -137,6 +137,19 @@ int ds2_gru_bidir_fwd(float* G, float* ghn, float* hout, const float* w_hh, int 
 int ds2_gru_bidir_bwd(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                       float* dh_ws, int T, int B, int H, void* stream);
 int ds2_transpose2d(const float* in, int rows, int cols, float* out, void* stream);
+/* Persistent form of the two calls above: ONE launch per layer pass; every workgroup keeps its slice
+ * of the recurrent weights in registers for all T steps and hands h_t (forward) / d(gh)_t (backward)
+ * to the other workgroups inside the launch (write-through stores + arrival counter).  Same
+ * arguments and results; sync_ws is a caller-owned device buffer of ds2_gru_sync_ws_bytes() bytes
+ * (zeroed by the call); its last 32-bit word is set to 1 if a bounded spin timed out (results are then
+ * invalid -- check it after synchronising).  Returns DS2_ERR_UNSUPPORTED for shapes outside
+ * ds2_gru_persistent_supported(B, H) (H % 16 == 0, 2*ceil(H/8) <= 240 workgroups, B <= 64). */
+size_t ds2_gru_sync_ws_bytes(void);
+int ds2_gru_persistent_supported(int B, int H);
+int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh, void* sync_ws, int T,
+                                 int B, int H, void* stream);
+int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* hout, const float* d_out,
+                                 const float* w_hh_t, void* sync_ws, int T, int B, int H, void* stream);
 
 /* ------------------------------------------------------------------ output head helpers
  * softmax over the last dim of (rows, A) (eval branch, codes/model.py:204-205) and the argmax

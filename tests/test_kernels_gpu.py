@@ -215,9 +215,13 @@ def test_bn1d_with_direction_sum(ops):
 
 
 # ------------------------------------------------------------------------------------------- GRU
+@pytest.mark.parametrize('mode', ['step', 'persistent'])
 @pytest.mark.parametrize('t,bsz,n_in,hid', [(9, 3, 24, 32), (6, 10, 40, 800), (5, 20, 16, 64), (4, 40, 16, 72),
-                                            (3, 64, 8, 800), (1, 2, 8, 16)])
-def test_gru_recurrence_fwd_bwd(ops, t, bsz, n_in, hid):
+                                            (3, 64, 8, 800), (1, 2, 8, 16), (40, 33, 8, 256), (25, 17, 8, 512)])
+def test_gru_recurrence_fwd_bwd(ops, monkeypatch, mode, t, bsz, n_in, hid):
+    if mode == 'persistent' and hid % 16 != 0:
+        pytest.skip('persistent kernel needs H % 16 == 0 (falls back to the per-step kernels)')
+    monkeypatch.setattr(ops, 'GRU_MODE', mode)
     torch.manual_seed(t * 100 + bsz)
     gru = torch.nn.GRU(n_in, hid, bidirectional=True, bias=False)
     x = torch.randn(t, bsz, n_in, requires_grad=True)
@@ -258,6 +262,34 @@ def test_gru_recurrence_fwd_bwd(ops, t, bsz, n_in, hid):
         hnext = hout[1, 1:].reshape((t - 1) * bsz, hid).contiguous()
         dw_hh_r = ops.gemm(dgh_r.contiguous(), hnext, trans_a=True)
         np.testing.assert_allclose(dw_hh_r.cpu().numpy(), gru.weight_hh_l0_reverse.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch):
+    """T = 746 steps of the real layer shape, three times over: every hand-off must be fresh (a stale h would
+    show up as an O(1) difference), and the bounded spins must never trip."""
+    t, bsz, hid = 746, 10, 800
+    torch.manual_seed(1)
+    k = 1.0 / hid ** 0.5
+    w_hh = ((torch.rand(2, 3 * hid, hid) * 2 - 1) * k).to(DEV)
+    w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
+    gi = torch.randn(t, bsz, 2, 3 * hid).to(DEV)
+    d_out = (0.1 * torch.randn(t, bsz, hid)).to(DEV)
+    res = {}
+    for mode in ('step', 'persistent', 'persistent', 'persistent'):
+        monkeypatch.setattr(ops, 'GRU_MODE', mode)
+        g = gi.clone()
+        ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
+        fwd = (g.clone(), ghn.clone(), hout.clone())
+        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
+        torch.cuda.synchronize()
+        ops.check_async_errors()
+        cur = fwd + (g, ghn)
+        if mode == 'step':
+            res = cur
+        else:
+            for a, b, tol in zip(cur, res, (2e-5, 2e-5, 2e-5, 2e-4, 2e-4)):
+                scale = float(b.abs().max())
+                assert float((a - b).abs().max()) <= tol * max(scale, 1.0)
 
 
 # ------------------------------------------------------------------------------------------- CTC
