@@ -311,8 +311,8 @@ class DeepSpeech(nn.Module):
         gv = lambda p: self._gview(gflat, p)                                        # noqa: E731
         head = self.fc[0].module
         d2 = d_acts.reshape(rows, ncls)
-        ops.gemm(d2, sv['xf'], trans_a=True, out=gv(head[1].weight))               # dW_fc = d^T xf
-        dxf = ops.gemm(d2, head[1].weight)                                          # (rows,H)
+        ops.gemm(d2, sv['xf'], trans_a=True, out=gv(head[1].weight), split_k=0)               # dW_fc = d^T xf
+        dxf = ops.gemm(d2, head[1].weight, split_k=0)                                          # (rows,H)
         last = sv['layers'][-1]['hout']
         dy = ops.bn1d_bwd(last[0], last[1], dxf, sv['mi_fc'], head[0].weight, rows, hid, gv(head[0].weight),
                           gv(head[0].bias))
@@ -341,15 +341,16 @@ class DeepSpeech(nn.Module):
                     a_g = gates.data_ptr() + d * 3 * hid * f4 + (step_g if d == 0 else 0)
                     a_n = ghn.data_ptr() + d * hid * f4 + (step_n if d == 0 else 0)
                     hp = hout[d].data_ptr() + (0 if d == 0 else bsz * hid * f4)
-                    ops.gemm_raw(1, 0, 2 * hid, hid, k, a_g, 6 * hid, hp, hid, g_hh[d].data_ptr(), hid)
-                    ops.gemm_raw(1, 0, hid, hid, k, a_n, 2 * hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4, hid)
+                    ops.gemm_raw(1, 0, 2 * hid, hid, k, a_g, 6 * hid, hp, hid, g_hh[d].data_ptr(), hid, split_k=0)
+                    ops.gemm_raw(1, 0, hid, hid, k, a_n, 2 * hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4, hid,
+                                 split_k=0)
             else:
                 g_hh[0].zero_()
                 g_hh[1].zero_()
             dgi = gates.view(rows, 6 * hid)
             g_ih = self._pair_view(gflat, r.weight_ih_l0, r.weight_ih_l0_reverse)
-            ops.gemm(dgi, rec['xin'].view(rows, n_in), trans_a=True, out=g_ih)      # dW_ih (both dirs)
-            dxin = ops.gemm(dgi, w_ih)                                              # (rows, n_in)
+            ops.gemm(dgi, rec['xin'].view(rows, n_in), trans_a=True, out=g_ih, split_k=0)      # dW_ih (both dirs)
+            dxin = ops.gemm(dgi, w_ih, split_k=0)                                              # (rows, n_in)
             if layer.batch_norm is not None:
                 bn = layer.batch_norm.module
                 below = sv['layers'][li - 1]['hout']

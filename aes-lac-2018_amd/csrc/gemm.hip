@@ -172,6 +172,15 @@ template <bool AK, bool BKc>
 int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float beta,
            int split_k, hipStream_t st) {
     const int tm = ds2_cdiv(M, BM), tn = ds2_cdiv(N, BN);
+    if (split_k == 0) {  // auto: fill the 256 CUs (2 workgroups each) when the output grid alone cannot
+        const int tiles = tm * tn;
+        split_k = 1;
+        if (tiles < 384 && K >= 512) {
+            split_k = ds2_cdiv(512, tiles);
+            const int max_split = K / 256 > 1 ? K / 256 : 1;
+            if (split_k > max_split) split_k = max_split;
+        }
+    }
     if (split_k < 1) split_k = 1;
     int kper = ds2_cdiv(ds2_cdiv(K, split_k), BK) * BK;
     if (kper < BK) kper = BK;
@@ -179,6 +188,8 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
     const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
     dim3 grid(tm * tn, nsplit), block(256);
     const int atomic = nsplit > 1 ? 1 : 0;
+    if (atomic && beta == 0.f)  // partial products are accumulated with atomics: start from zero
+        (void)hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
     if (vec)
         hipLaunchKernelGGL((gemm_f32_kernel<AK, BKc, true>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc,
                            beta, tn, kper, atomic);
@@ -195,7 +206,7 @@ extern "C" int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
     DS2_CHECK_ARG(M > 0 && N > 0 && K > 0);
     DS2_CHECK_ARG(A && B && C);
     DS2_CHECK_ARG(beta == 0.f || beta == 1.f);
-    DS2_CHECK_ARG(split_k <= 1 || beta == 1.f);
+    DS2_CHECK_ARG(split_k >= 0);
     DS2_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N);
     hipStream_t st = (hipStream_t)stream;
     if (!trans_a && !trans_b) launch<true, false>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);

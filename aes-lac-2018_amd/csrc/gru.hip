@@ -287,9 +287,11 @@ constexpr unsigned long long SPIN_TICKS = 50000000ull;  // 0.5 s of the 100 MHz 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int NSHARD = 8;  // arrival counters per direction (workgroup x -> shard x % 8), each on its own 128-B line:
+                           // 100 arrivals on ONE word serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
 struct SyncWs {            // lives in caller-provided device memory, zeroed before every launch
-    unsigned int arrive[2][32];   // one counter per direction, 128 B apart
-    unsigned int error;           // set to 1 on a spin timeout
+    unsigned int arrive[2][NSHARD][32];
+    unsigned int error;    // set to 1 on a spin timeout
 };
 
 __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
@@ -300,15 +302,21 @@ __device__ __forceinline__ void store_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// thread 0 only: wait until *ctr >= target; false on timeout
-__device__ __forceinline__ bool wait_arrivals(unsigned int* ctr, unsigned int target, unsigned int* err) {
+// wave 0 only (all 64 lanes call it): lane l < NSHARD polls shard l until it holds step * (slices in that shard)
+// arrivals; returns false on timeout.
+__device__ __forceinline__ bool wait_arrivals(unsigned int* shards, int step, int nslice, int lane,
+                                              unsigned int* err) {
+    const unsigned int target = (unsigned int)step * (unsigned int)((nslice - lane + NSHARD - 1) / NSHARD);
+    const bool poller = lane < NSHARD && lane < nslice;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        const unsigned int v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v >= target) return true;
+        bool ok = true;
+        if (poller)
+            ok = __hip_atomic_load(shards + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+        if (__all(ok)) return true;
         __builtin_amdgcn_s_sleep(1);
         if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
     }
@@ -350,7 +358,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
     const int gb = gbt * 16 + nn, gj = j0 + jj;
     const bool gate_ok = (gbt < NBT) && (gb < B) && (gj < H);
     float hp = 0.f;                                     // this thread's h_{t-1}, carried in a register
-    unsigned int* ctr = &sync->arrive[dir][0];
+    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             gi_n = G[gbase + 2 * H];
         }
         if (s > 0) {
-            if (tid == 0 && !wait_arrivals(ctr, (unsigned int)s * nslice, &sync->error)) abort_flag = 1;
+            if (wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0) abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
             const int tprev = dir == 0 ? t - 1 : t + 1;
@@ -455,7 +464,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
     const int gb = gbt * 16 + nn, gj = j0 + jj;
     const bool gate_ok = (gbt < NBT) && (gb < B) && (gj < H);
     float dhz = 0.f;                                    // dh * z carried to the next (earlier) step
-    unsigned int* ctr = &sync->arrive[dir][0];
+    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
             if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
         }
         if (s > 0) {
-            if (tid == 0 && !wait_arrivals(ctr, (unsigned int)s * nslice, &sync->error)) abort_flag = 1;
+            if (wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0) abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
             // dGH of step tnext: [dr_pre | dz_pre] from G, d(gh_n) from ghn -- all stored sc1 by their owners

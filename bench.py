@@ -103,8 +103,9 @@ def cpu_baseline(bins, budget_s=25.0):
                       % (len(used), frames, secs)}
 
 
-def gru_step_roofline(model, bsz, t):
-    """Live HIP-event timing of the dominant kernel: the backward GRU time-step (one launch per step)."""
+def gru_pass_roofline(model, bsz, t):
+    """Live HIP-event timing of the dominant kernels: one persistent BiGRU layer pass (ONE launch covering
+    all T steps of both directions), forward and backward, on torch's current stream = the launch stream."""
     from ds2hip import ops
     hid = model._rnn_hidden_size
     dev = model._flat_p.device
@@ -112,34 +113,26 @@ def gru_step_roofline(model, bsz, t):
     w_hh = model._pair(r.weight_hh_l0, r.weight_hh_l0_reverse).view(2, 3 * hid, hid)
     w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
     gates = 0.1 * torch.randn(t, bsz, 2, 3 * hid, device=dev)
-    res = {}
-    for name in ('fwd', 'bwd'):
-        times = []
-        for _ in range(3):
-            g = gates.clone()
-            ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
-            if name == 'bwd':
-                d_out = 0.01 * torch.randn(t, bsz, hid, device=dev)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            if name == 'fwd':
-                g2 = gates.clone()
-                e0.record()
-                ops.gru_bidir_fwd(g2, w_hh, t, bsz, hid)
-                e1.record()
-            else:
-                e0.record()
-                ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
-                e1.record()
-            torch.cuda.synchronize()
-            times.append(e0.elapsed_time(e1) * 1e-3 / t)
-        res[name] = float(np.median(times))
-    k = {'fwd': hid, 'bwd': 3 * hid}
-    n = {'fwd': 3 * hid, 'bwd': hid}
+    d_out = 0.01 * torch.randn(t, bsz, hid, device=dev)
+    res = {'fwd': [], 'bwd': []}
+    for _ in range(5):
+        g = gates.clone()
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
+        e[1].record()
+        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
+        e[2].record()
+        torch.cuda.synchronize()
+        ops.check_async_errors()
+        res['fwd'].append(e[0].elapsed_time(e[1]) * 1e-3)
+        res['bwd'].append(e[1].elapsed_time(e[2]) * 1e-3)
+    flop = 2.0 * 2 * bsz * hid * 3 * hid * t                           # both directions, all T steps
     out = {}
     for name in ('fwd', 'bwd'):
-        flop = 2.0 * 2 * bsz * k[name] * n[name]                      # both directions, one launch
-        out[name] = (flop / res[name] / 1e12, res[name])
+        dur = float(np.median(res[name]))
+        out[name] = (flop / dur / 1e12, dur, flop)
     return out
 
 
@@ -216,9 +209,9 @@ def main():
 
     value = frames / dt
     step_tflops = osteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12 / world    # per GPU, padded steps included
-    t_mid = 400
-    roof = gru_step_roofline(model, bsz, t_mid)
-    ach, dur = roof['bwd']
+    t_mean = int(round(np.mean([out_steps_of(b) / len(b[0]) for b in mine])))
+    roof = gru_pass_roofline(model, bsz, t_mean)
+    ach, dur, flop = roof['bwd']
     result = {
         'metric': 'train frames/sec, DeepSpeech2 5xBiGRU-800',
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -229,12 +222,15 @@ def main():
                                'frontend, CTC, clip+SGD' % bsz,
                    'batch_per_gpu': bsz, 'global_batch': bsz * world, 'parallelism': 'dp%d' % world,
                    'last_loss': round(float(loss), 4)},
-        'roofline': {'bound': 'mfma', 'kernel': 'gru_bwd_step_kernel (one launch per time step, both directions)',
+        'roofline': {'bound': 'mfma',
+                     'kernel': 'gru_bwd_persistent_kernel (one launch = all T=%d steps of a BiGRU layer, both '
+                               'directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None,
-                     'avg_launch_us': round(dur * 1e6, 3),
-                     'fwd_step_tflops': round(roof['fwd'][0], 3), 'fwd_step_us': round(roof['fwd'][1] * 1e6, 3),
-                     'flop_per_launch': 2.0 * 2 * bsz * 2400 * 800,
+                     'avg_launch_us': round(dur * 1e6, 1), 'us_per_time_step': round(dur * 1e6 / t_mean, 3),
+                     'flop_per_launch': flop,
+                     'fwd_kernel_tflops': round(roof['fwd'][0], 3),
+                     'fwd_us_per_time_step': round(roof['fwd'][1] * 1e6 / t_mean, 3),
                      'whole_step_tflops_per_gpu': round(step_tflops, 3),
                      'whole_step_frac_of_f32_mfma_peak': round(step_tflops / PEAK_F32_MFMA_TFLOPS, 5)},
     }

@@ -55,8 +55,10 @@ int ds2_spectrogram_fwd(const float* wav, const int64_t* wav_offsets, int B, int
  * C[M,N] = op(A) * op(B) + beta * C, row-major with leading dimensions.  op(A)=A (M x K, lda) or
  * A^T (A stored K x M); op(B)=B (K x N, ldb) or B^T (B stored N x K).  beta is 0 or 1.
  * Stands in for the cuBLAS calls behind nn.Linear / nn.GRU's input projection
- * (codes/model.py:51-52,178-180).  split_k > 1 accumulates partial products with atomics
- * (requires beta handled by the caller: C must already hold beta*C, pass beta=1).
+ * (codes/model.py:51-52,178-180).  split_k > 1 splits K over workgroups and accumulates the
+ * partial products with float atomics (C is zero-filled first when beta = 0; the last bits then
+ * depend on arrival order); split_k = 0 picks a split that fills the chip when M*N alone gives
+ * fewer than ~384 tiles (the dW = dG^T X products: small M*N, K = T*B).
  */
 int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
                  int ldb, float* C, int ldc, float beta, int split_k, void* stream);
