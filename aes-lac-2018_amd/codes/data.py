@@ -31,3 +31,54 @@ def collate_audio(batch):
     flat = [int(v) for b in batch for v in b[1]]
     sizes = torch.tensor([len(b[1]) for b in batch], dtype=torch.int)
     return wavs, torch.tensor(flat, dtype=torch.int), sizes
+
+
+class AudioDataset(torch.utils.data.Dataset):
+    """Manifest CSV ``audio_path,transcript_path,duration`` (reference ``codes/data.py:13-70``; no zip support)."""
+
+    def __init__(self, data_dir, manifest_filepath, transforms=None, target_transforms=None):
+        import os
+        self.data_dir, self.manifest_filepath = data_dir, manifest_filepath
+        with open(manifest_filepath) as f:
+            rows = [line.strip().split(',') for line in f if line.strip()]
+        self.durations = [float(r[2]) for r in rows]
+        self.data = [(os.path.join(data_dir, r[0]), os.path.join(data_dir, r[1])) for r in rows]
+        self.transforms, self.target_transforms = transforms, target_transforms
+
+    def __getitem__(self, index):
+        audio, target = self.data[index]
+        if self.transforms is not None:
+            audio = self.transforms(audio)
+        if self.target_transforms is not None:
+            target = self.target_transforms(target)
+        return audio, target
+
+    def __len__(self):
+        return len(self.data)
+
+
+class AudioDataLoader(torch.utils.data.DataLoader):
+    """DataLoader whose collate is the reference's (``codes/data.py:96-166``).
+
+    ``raw_audio=True`` keeps clips as raw 1-D waveforms (``collate_audio``) so the spectrogram runs on the GPU
+    after collate (``BatchSpectrogram``) instead of per utterance in worker processes."""
+
+    def __init__(self, *args, **kwargs):
+        raw = kwargs.pop('raw_audio', False)
+        kwargs.pop('num_tasks', None)
+        kwargs['collate_fn'] = _collate_raw if raw else _collate_spect
+        super().__init__(*args, **kwargs)
+
+
+def _labels_list(t):
+    import numpy as np
+    return [int(v) for v in np.asarray(t).reshape(-1)]
+
+
+def _collate_spect(batch):
+    return collate([(s, _labels_list(t)) for s, t in batch])
+
+
+def _collate_raw(batch):
+    wavs, targets, sizes = collate_audio([(w, _labels_list(t)) for w, t in batch])
+    return wavs, targets, None, sizes

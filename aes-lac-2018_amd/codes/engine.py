@@ -45,14 +45,15 @@ class Trainer(object):
         self.iteration = 0
         self.data_time = 0.0
         self.last_grad_norm = None
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.overlap = overlap_allreduce and self.world > 1
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.overlap = overlap_allreduce and self.distributed
         self._comm_stream = None
         self._buf = None
         self._first = True
         self._sumsq = None
         model._ensure_flat()
-        if self.world > 1:                       # DDP construction: rank 0's parameters and buffers win
+        if self.distributed:                     # DDP construction: rank 0's parameters and buffers win
             dist.broadcast(model._flat_p, 0)
             for b in model.buffers():
                 dist.broadcast(b, 0)
@@ -111,7 +112,7 @@ class Trainer(object):
         hook = self._bucket_hook() if self.overlap else None
         costs, _ = self._forward_backward(inputs, loss_fn, hook)
         gflat = model.flat_grad()
-        if self.world > 1:
+        if self.distributed:
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self._comm_stream)
             else:

@@ -240,16 +240,23 @@ class DeepSpeech(nn.Module):
         assert t > 0, 'input too short for the conv stack'
         sv = {'t_in': t_in, 't1': t1, 't': t, 'bsz': bsz}
         c = self.conv
+        # fine-tuning with frozen conv layers keeps their BatchNorm in inference mode (training_utils.py:52-54,73)
+        conv_frozen = getattr(c[1], 'frozen_stats', False) or getattr(c[4], 'frozen_stats', False)
+        conv_train = training and not conv_frozen
+        for mod in list(self.rnns.modules()) + list(self.fc.modules()):
+            if getattr(mod, 'frozen_stats', False):
+                raise NotImplementedError('freezing BatchNorm statistics is supported for the conv block only')
         xt = ops.transpose_btf(x)                                                   # (B,161,T_in)
         y1 = ops.conv_fwd(1, xt, c[0].weight, c[0].bias, t_in)                      # (B,32,61,T1)
-        mi1 = ops.bn2d_stats(y1, c[1].running_mean, c[1].running_var, training)
+        mi1 = ops.bn2d_stats(y1, c[1].running_mean, c[1].running_var, conv_train)
         a1 = ops.bn2d_apply_htanh(y1, mi1, c[1].weight, c[1].bias, layout_tbf=False)
         y2 = ops.conv_fwd(2, a1, c[3].weight, c[3].bias, t1)                        # (B,32,21,T)
-        mi2 = ops.bn2d_stats(y2, c[4].running_mean, c[4].running_var, training)
+        mi2 = ops.bn2d_stats(y2, c[4].running_mean, c[4].running_var, conv_train)
         xin = ops.bn2d_apply_htanh(y2, mi2, c[4].weight, c[4].bias, layout_tbf=True)  # (T,B,672)
-        if training:
+        if conv_train:
             c[1].num_batches_tracked += 1
             c[4].num_batches_tracked += 1
+        sv['conv_frozen'] = conv_frozen
         sv.update(xt=xt, y1=y1, mi1=mi1, a1=a1, y2=y2, mi2=mi2)
         rows = t * bsz
         layers = []
@@ -363,6 +370,12 @@ class DeepSpeech(nn.Module):
                 grad_ready(*self._span(first, r.weight_hh_l0_reverse))
             rec.clear()
         c = self.conv
+        if sv.get('conv_frozen', False):             # frozen conv block: nothing upstream needs a gradient
+            lo, hi = self._span(c[0].weight, c[4].bias)
+            gflat[lo:hi].zero_()
+            if grad_ready is not None:
+                grad_ready(lo, hi)
+            return
         d_a2 = ops.transpose2d(dy, t, bsz * self._rnn_input_size).view(bsz, 32, 21, t)   # (T,B,672) -> (B,32,21,T)
         d_y2 = ops.bn2d_htanh_bwd(sv['y2'], d_a2, sv['mi2'], c[4].weight, c[4].bias, gv(c[4].weight), gv(c[4].bias))
         ops.conv_wgrad(2, sv['a1'], d_y2, t1, gv(c[3].weight), gv(c[3].bias))

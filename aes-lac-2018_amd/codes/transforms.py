@@ -77,3 +77,91 @@ class BatchSpectrogram(object):
         inputs = ops.spectrogram(flat, offs_d, t_max, self.normalize, self.eps)
         pct = torch.tensor([f / float(t_max) for f in frames], dtype=torch.float32)
         return inputs, pct
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Host-side neighbours of the hot path: waveform loading and transcript -> labels.
+# ---------------------------------------------------------------------------------------------------------
+class Compose(object):
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+class ToTensor(object):
+    """16-bit PCM mono WAV -> 1-D float tensor (reference ``codes/transforms.py:130-224``).
+
+    The reference decodes with torchaudio/sox (absent here) and augments with the ``sox`` CLI (tempo + gain);
+    this loader reads PCM16 with the standard library and scales to [-1, 1).  ``augment=True`` is refused:
+    sox's WSOLA tempo change has no parity target on this box."""
+
+    def __init__(self, sample_rate=16000, augment=False, tempo_range=(0.85, 1.15), gain_range=(-6, 8)):
+        if augment:
+            raise NotImplementedError('sox tempo/gain augmentation is out of scope (no sox on this box)')
+        self.sample_rate, self.augment = sample_rate, augment
+        self.tempo_range, self.gain_range = tempo_range, gain_range
+
+    def __call__(self, path):
+        import wave
+
+        import numpy as np
+        with wave.open(path, 'rb') as w:
+            assert w.getframerate() == self.sample_rate, 'sample rate mismatch'
+            assert w.getsampwidth() == 2 and w.getnchannels() == 1, 'expected 16-bit mono PCM'
+            pcm = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2')
+        return torch.from_numpy(pcm.astype('float32') / 32768.0)
+
+
+_ACCENT_FOLD = {'À': 'A', 'Á': 'A', 'Â': 'A', 'Ã': 'A', 'Ä': 'A', 'Ç': 'C', 'È': 'E', 'É': 'E', 'Ê': 'E', 'Ë': 'E',
+                'Ì': 'I', 'Í': 'I', 'Î': 'I', 'Ï': 'I', 'Ñ': 'N', 'Ò': 'O', 'Ó': 'O', 'Ô': 'O', 'Õ': 'O', 'Ö': 'O',
+                'Ù': 'U', 'Ú': 'U', 'Û': 'U', 'Ü': 'U'}
+
+
+class ToLabel(object):
+    """Transcript (string or path) -> (L,1) int array of label ids (reference ``codes/transforms.py:295-392``).
+
+    Upper-cases, optionally folds accents (a fixed Latin-1 table stands in for ``unidecode``), drops every
+    character that is not in the label set.  Number-to-words conversion (``num2words``, absent here) is NOT
+    applied: digits are simply not in the alphabets and get filtered -- a documented deviation."""
+
+    def __init__(self, labels='labels.en.json', to_upper=True, one_hot=False, convert_number_to_words=True, lang=None,
+                 remove_accents=True, dtype=None):
+        import os
+
+        import numpy as np
+
+        from .preprocessing import OrderedLabelEncoder
+        from .utils.io_utils import read_labels
+        if one_hot:
+            raise NotImplementedError('one-hot targets are not used by the CTC path')
+        if isinstance(labels, str) and os.path.isfile(labels):
+            labels_list = read_labels(labels)
+            lang = lang or labels.split('.')[-2]
+        else:
+            labels_list = list(labels)
+        self._labels, self._lang, self._to_upper = labels, lang, to_upper
+        self._remove_accents = remove_accents
+        self._dtype = dtype or np.int64
+        self.label_encoder = OrderedLabelEncoder().fit(labels_list)
+        self._known = set(self.label_encoder.classes_.tolist())
+
+    def __call__(self, x):
+        import os
+
+        import numpy as np
+        if isinstance(x, bytes):
+            x = x.decode('utf8')
+        if os.path.isfile(x):
+            with open(x, 'r', encoding='utf8') as f:
+                x = f.readline().strip()
+        if self._to_upper:
+            x = x.upper()
+        if self._remove_accents:
+            x = ''.join(_ACCENT_FOLD.get(c, c) for c in x)
+        chars = [c for c in x if c in self._known]
+        ids = np.asarray(self.label_encoder.transform(chars), dtype=self._dtype).reshape(-1)
+        return ids[:, np.newaxis]

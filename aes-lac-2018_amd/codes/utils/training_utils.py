@@ -1,0 +1,142 @@
+"""Factories driven by the JSON config (reference ``codes/utils/training_utils.py``).
+
+Config schema (unchanged): ``model{name, langs, freeze_layers, map_fc, params}``,
+``training{num_epochs, batch_size, max_norm, augment, finetune}``, ``optimizer{name, params, per_layer_lr}``,
+``scheduler{name, params}``.  Broken branches of the reference are implemented to their evident intent
+(SURVEY.md section 4): ``langs[0]`` is the fine-tune target language, the new FC layer's *weight* is
+normally initialised.
+"""
+import json
+import logging
+import os
+
+import torch
+
+from .. import transforms
+from ..data import AudioDataLoader, AudioDataset
+from ..model import DeepSpeech, _BatchNormParams, _LinearParams
+from ..sampler import BucketingSampler, DistributedBucketingSampler
+
+LOG = logging.getLogger('aes-lac-2018')
+NUM_CLASSES = {'pt_BR': 43, 'en': 29}
+
+
+def get_default_transforms(data_dir, config, gpu_frontend=True):
+    """Waveform loader (+ per-utterance spectrogram when ``gpu_frontend`` is False) and one ToLabel per language
+    (training_utils.py:18-34).  With ``gpu_frontend`` the spectrogram runs batched on the device after collate."""
+    augment = bool(config.training.get('augment', False))
+    if augment:
+        LOG.warning('sox tempo/gain augmentation is not available on this box; training without it')
+    load = transforms.ToTensor(augment=False)
+    chain = [load] if gpu_frontend else [load, transforms.ToSpectrogram(librosa_compat=True)]
+    train_t, val_t = transforms.Compose(chain), transforms.Compose(chain)
+    target_t = [transforms.ToLabel(os.path.join(data_dir, 'labels.{}.json'.format(lang)), lang=lang,
+                                   remove_accents=(lang != 'pt_BR')) for lang in config.model.langs]
+    return train_t, val_t, target_t
+
+
+def get_model(model_dict):
+    if isinstance(model_dict.langs, (tuple, set, list)) and len(model_dict.langs) > 1:
+        raise NotImplementedError('multi-task models are out of scope (SURVEY.md section 2 row 1)')
+    params = dict(model_dict.get('params', {}) or {})
+    params.setdefault('num_classes', NUM_CLASSES[model_dict.langs[0]])
+    model_dict['params'] = params
+    return DeepSpeech(**params)
+
+
+class _FrozenMarker(object):
+    """Modules whose BatchNorm must stay in inference mode are tagged so the model can honour it."""
+
+
+def _freeze_layers(model, freeze_layers):
+    if freeze_layers is None:
+        return model
+    if isinstance(freeze_layers, str):
+        freeze_layers = [freeze_layers]
+    count = 0
+    for name in freeze_layers:
+        target = model if name == 'all' else getattr(model, name)
+        if isinstance(target, torch.nn.Module):
+            for m in target.modules():
+                if isinstance(m, _BatchNormParams):
+                    m.frozen_stats = True            # reference: BatchNorm of frozen layers put in eval mode (:52-54,73)
+            params = target.parameters()
+        else:
+            params = [target]
+        for p in params:
+            count += p.numel()
+            p.requires_grad = False
+    LOG.info('\tFreezed {} parameters'.format(count))
+    return model
+
+
+def finetune_model(model, obj):
+    """Freeze layers and, when the alphabet changes, swap the last FC (training_utils.py:87-122)."""
+    freeze_layers = obj.get('freeze_layers', None)
+    lang = obj['langs'][0] if 'langs' in obj else obj['lang']
+    num_classes = NUM_CLASSES[lang]
+    map_fc = obj.get('map_fc', None)
+    model = _freeze_layers(model, freeze_layers)
+    head = model.fc[0].module
+    old = head[1]
+    if old.out_features != num_classes or (freeze_layers and freeze_layers[0] == 'all'):
+        LOG.info('\tChanging the last FC layer')
+        new = _LinearParams(old.in_features, num_classes).to(old.weight.device)
+        with torch.no_grad():
+            torch.nn.init.normal_(new.weight, 0, 0.01)
+            if map_fc is not None:
+                pairs = json.load(open(map_fc))
+                old_idx, new_idx = zip(*pairs)
+                new.weight.index_copy_(0, torch.tensor(new_idx, device=new.weight.device),
+                                       old.weight.detach().index_select(0, torch.tensor(old_idx,
+                                                                                        device=old.weight.device)))
+        head[1] = new
+        model._num_classes = num_classes
+        model._flat_p = None                 # parameters changed: re-pack lazily
+    return model
+
+
+def get_optimizer(params, obj):
+    return getattr(torch.optim, obj.get('name', 'SGD'))(params, **obj.params)
+
+
+def get_scheduler(optimizer, obj):
+    return getattr(torch.optim.lr_scheduler, obj.get('name', 'ExponentialLR'))(optimizer, **obj.params)
+
+
+def get_per_params_lr(model, obj):
+    """Per-layer learning-rate groups (training_utils.py:133-159): [[name, lr], ..., ['base']]."""
+    per_layer_lr = obj.get('per_layer_lr', None)
+    if per_layer_lr is None:
+        return model.parameters()
+    groups, taken, has_base = [], set(), False
+    for conf in per_layer_lr:
+        if conf[0] == 'base':
+            has_base = True
+            continue
+        ps = list(getattr(model, conf[0]).parameters())
+        g = {'params': ps}
+        if len(conf) > 1:
+            g['lr'] = conf[1]
+        groups.append(g)
+        taken.update(id(p) for p in ps)
+    if has_base:
+        groups.append({'params': [p for p in model.parameters() if id(p) not in taken]})
+    return groups
+
+
+def get_data_loaders(train_transforms, val_transforms, target_transforms, args, raw_audio=True):
+    if not isinstance(target_transforms, (list, tuple)):
+        target_transforms = [target_transforms]
+    if len(target_transforms) != 1:
+        raise NotImplementedError('multi-task data loading is out of scope')
+    train_set = AudioDataset(args.data_dir, args.train_manifest[0], train_transforms, target_transforms[0])
+    val_set = AudioDataset(args.data_dir, args.val_manifest[0], val_transforms, target_transforms[0])
+    bsz = args.config.training.batch_size
+    if args.distributed:
+        sampler = DistributedBucketingSampler(train_set, batch_size=bsz)
+    else:
+        sampler = BucketingSampler(train_set, batch_size=bsz)
+    train_loader = AudioDataLoader(train_set, num_workers=args.num_workers, batch_sampler=sampler, raw_audio=raw_audio)
+    val_loader = AudioDataLoader(val_set, batch_size=bsz, num_workers=args.num_workers, raw_audio=raw_audio)
+    return train_loader, val_loader
