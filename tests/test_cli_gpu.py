@@ -59,7 +59,7 @@ def test_train_then_test_cli(tmp_path):
 
 def test_trainer_distributed_path_single_rank():
     """With a process group initialised the trainer broadcasts, all-reduces per-layer slices on a side stream and
-    folds 1/world into the update: with world = 1 the result must equal the non-distributed step exactly."""
+    folds 1/world into the update: with world = 1 the result must equal the non-distributed step (up to atomic-add ordering)."""
     import torch.distributed as dist
     from codes.engine import Trainer
     from codes.model import DeepSpeech
@@ -90,5 +90,6 @@ def test_trainer_distributed_path_single_rank():
         assert tr.distributed and tr.overlap and tr._comm_stream is not None
     finally:
         dist.destroy_process_group()
-    assert losses == ref_losses
-    assert torch.equal(p, ref_p)
+    assert losses == pytest.approx(ref_losses, rel=1e-6)
+    # split-K GEMMs and the conv wgrad accumulate with float atomics: the last bits depend on arrival order
+    assert float((p - ref_p).abs().max()) < 1e-6
