@@ -1,0 +1,415 @@
+// Persistent BiGRU recurrence kernels for gfx950 (one launch per layer pass).
+#include <stddef.h>
+#include <stdlib.h>
+
+#include "ds2_common.h"
+
+// ==========================================================================================================
+// Persistent recurrence: ONE launch per layer pass, recurrent weights resident in VGPRs for all T steps.
+//
+// The launch-per-step kernels above re-stream W_hh (15.4 MB for both directions at H = 800) from the
+// Infinity Cache every step because nothing keeps a workgroup's slice in its XCD's L2 across launches
+// (rocprof: TCC_MISS ~ 18 MB per launch), which bounds a step at ~8 us.  Here every workgroup keeps its
+// slice as MFMA A-operand fragments in registers (8 waves x KBW k-blocks of 16), so a step only moves the
+// hidden state: each workgroup publishes its JU x B new values with write-through (sc1) stores, one lane
+// adds to a per-direction arrival counter after every storing wave has drained (s_waitcnt vmcnt(0)) and
+// the workgroup has met at a barrier, and consumers poll that counter with relaxed agent-scope loads,
+// meet at a barrier, then read the full h_{t-1} with sc1 buffer loads straight into MFMA B-operand
+// registers (cdna_hip_programming.md Guideline 16, counter form; MI355X_MICROARCH.md "Valid forms" row 1:
+// one workgroup per CU, every handed-off byte stored AND loaded sc1).  All workgroups must be co-resident:
+// grid = 2 * ceil(H/8) <= 240 workgroups of 512 threads.  Every spin is bounded by a wall-clock timeout
+// that raises a flag the host checks (no hang on a lost workgroup).
+// ==========================================================================================================
+namespace {
+
+constexpr int NWP = 8;                    // waves per persistent workgroup (2 per SIMD)
+constexpr int PJU = 8;                    // hidden units per workgroup
+constexpr unsigned long long SPIN_TICKS = 50000000ull;  // 0.5 s of the 100 MHz real-time counter
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NSHARD = 8;  // arrival counters per direction (workgroup x -> shard x % 8), each on its own 128-B line:
+                           // 100 arrivals on ONE word serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
+struct SyncWs {            // lives in caller-provided device memory, zeroed before every launch
+    unsigned int arrive[2][NSHARD][32];
+    unsigned int error;    // set to 1 on a spin timeout
+};
+
+__device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ void store_sc1(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0 only (all 64 lanes call it): lane l < NSHARD polls shard l until it holds step * (slices in that shard)
+// arrivals; returns false on timeout.
+__device__ __forceinline__ bool wait_arrivals(unsigned int* shards, int step, int nslice, int lane,
+                                              unsigned int* err) {
+    const unsigned int target = (unsigned int)step * (unsigned int)((nslice - lane + NSHARD - 1) / NSHARD);
+    const bool poller = lane < NSHARD && lane < nslice;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        bool ok = true;
+        if (poller)
+            ok = __hip_atomic_load(shards + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+        if (__all(ok)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
+            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+
+template <int NBT, int KBW>
+__global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                      float* __restrict__ hout,
+                                                                      const float* __restrict__ w_hh,
+                                                                      SyncWs* __restrict__ sync, int T, int B, int H, int dbg) {
+    __shared__ float red[NWP][2][NBT][16][17];
+    __shared__ int abort_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y, nslice = gridDim.x;
+    const int j0 = blockIdx.x * PJU;
+    const int m = lane & 15, q = lane >> 4;
+    const int nkb = H >> 4;
+    if (tid == 0) abort_flag = 0;
+
+    // ---- resident weights: tile 0 rows = [r units | z units], tile 1 rows = [n units | unused]
+    f32x4 wreg[2][KBW];
+    {
+        const int mj = m & 7, hi = m >> 3;
+        const bool unit_ok = (j0 + mj) < H;
+        const float* row0 = w_hh + ((size_t)dir * 3 * H + (size_t)(hi ? H : 0) + j0 + mj) * H;      // r or z
+        const float* row1 = w_hh + ((size_t)dir * 3 * H + (size_t)2 * H + j0 + mj) * H;              // n
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) {
+            const int kb = wave + NWP * i;
+            const bool ok = kb < nkb && unit_ok;
+            const int k = kb * 16 + q * 4;
+            wreg[0][i] = ok ? *reinterpret_cast<const f32x4*>(row0 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wreg[1][i] = (ok && hi == 0) ? *reinterpret_cast<const f32x4*>(row1 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // ---- gate-thread role
+    const int jj = tid & 7, nn = (tid >> 3) & 15, gbt = tid >> 7;
+    const int gb = gbt * 16 + nn, gj = j0 + jj;
+    const bool gate_ok = (gbt < NBT) && (gb < B) && (gj < H);
+    float hp = 0.f;                                     // this thread's h_{t-1}, carried in a register
+    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? s : T - 1 - s;
+        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
+        size_t gbase = 0;
+        if (gate_ok) {                                  // independent of h: issue before the wait
+            gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
+            gi_r = G[gbase];
+            gi_z = G[gbase + H];
+            gi_n = G[gbase + 2 * H];
+        }
+        if (s > 0) {
+            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+                abort_flag = 1;
+            __syncthreads();
+            if (abort_flag) return;
+            const int tprev = dir == 0 ? t - 1 : t + 1;
+            const float* hprev = hout + ((size_t)dir * T + tprev) * B * H;
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hprev), 0, B * H * 4, 0x00020000);
+#pragma unroll 1
+            for (int bt = 0; bt < ((dbg & 2) ? 0 : NBT); ++bt) {
+                const int b = bt * 16 + m;
+                f32x4 bf[KBW];
+#pragma unroll
+                for (int i = 0; i < KBW; ++i) {
+                    const int kb = wave + NWP * i;
+                    const bool ok = (kb < nkb) && (b < B);
+                    bf[i] = ok ? load_sc1_b128(rsrc, (b * H + kb * 16 + q * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+                for (int i = 0; i < KBW; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][i][e], bf[i][e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[1][i][e], bf[i][e], acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[wave][0][bt][4 * q + r][m] = acc0[r];
+                    red[wave][1][bt][4 * q + r][m] = acc1[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (gate_ok) {
+            float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
+            if (s > 0) {
+#pragma unroll
+                for (int w = 0; w < NWP; ++w) {
+                    gh_r += red[w][0][gbt][jj][nn];
+                    gh_z += red[w][0][gbt][8 + jj][nn];
+                    gh_n += red[w][1][gbt][jj][nn];
+                }
+            }
+            const float r = 1.f / (1.f + expf(-(gi_r + gh_r)));
+            const float z = 1.f / (1.f + expf(-(gi_z + gh_z)));
+            const float n = tanhf(gi_n + r * gh_n);
+            const float h = (1.f - z) * n + z * hp;
+            hp = h;
+            store_sc1(&hout[(((size_t)dir * T + t) * B + gb) * H + gj], h);   // handed to every other workgroup
+            G[gbase] = r;
+            G[gbase + H] = z;
+            G[gbase + 2 * H] = n;
+            ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = gh_n;
+        }
+        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NBT, int KBW>
+__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                      const float* __restrict__ hout,
+                                                                      const float* __restrict__ d_out,
+                                                                      const float* __restrict__ w_hh_t,
+                                                                      SyncWs* __restrict__ sync, int T, int B, int H, int dbg) {
+    __shared__ float red[NWP][NBT][16][17];
+    __shared__ int abort_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y, nslice = gridDim.x;
+    const int j0 = blockIdx.x * PJU;
+    const int m = lane & 15, q = lane >> 4;
+    const int K = 3 * H, nkb = K >> 4;
+    if (tid == 0) abort_flag = 0;
+
+    f32x4 wreg[KBW];                                   // rows m < 8: column (j0+m) of W_hh = row of w_hh_t
+    {
+        const bool row_ok = (m < PJU) && (j0 + m < H);
+        const float* row = w_hh_t + ((size_t)dir * H + j0 + (m & 7)) * K;
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) {
+            const int kb = wave + NWP * i;
+            wreg[i] = (row_ok && kb < nkb) ? *reinterpret_cast<const f32x4*>(row + kb * 16 + q * 4)
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const int jj = tid & 7, nn = (tid >> 3) & 15, gbt = tid >> 7;
+    const int gb = gbt * 16 + nn, gj = j0 + jj;
+    const bool gate_ok = (gbt < NBT) && (gb < B) && (gj < H);
+    float dhz = 0.f;                                    // dh * z carried to the next (earlier) step
+    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? T - 1 - s : s;
+        const int tnext = dir == 0 ? t + 1 : t - 1;
+        const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
+        // saved activations of step t (written by the forward pass, an earlier launch): plain loads
+        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
+        size_t row = 0, gbase = 0;
+        if (gate_ok) {
+            row = ((size_t)t * B + gb) * 2 + dir;
+            gbase = row * 3 * H + gj;
+            dh = d_out[((size_t)t * B + gb) * H + gj];
+            r = G[gbase];
+            z = G[gbase + H];
+            n = G[gbase + 2 * H];
+            gn = ghn[row * H + gj];
+            if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
+        }
+        if (s > 0) {
+            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+                abort_flag = 1;
+            __syncthreads();
+            if (abort_flag) return;
+            // dGH of step tnext: [dr_pre | dz_pre] from G, d(gh_n) from ghn -- all stored sc1 by their owners
+            const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+                G + (size_t)tnext * B * 6 * H, 0, B * 6 * H * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
+                ghn + (size_t)tnext * B * 2 * H, 0, B * 2 * H * 4, 0x00020000);
+#pragma unroll 1
+            for (int bt = 0; bt < ((dbg & 2) ? 0 : NBT); ++bt) {
+                const int b = bt * 16 + m;
+                // with several batch tiles the fragments are fetched in chunks to stay inside 256 VGPRs
+                constexpr int CH = (NBT > 1 && KBW > 10) ? 10 : KBW;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i0 = 0; i0 < KBW; i0 += CH) {
+                    f32x4 bf[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int i = i0 + c;
+                        const int kb = wave + NWP * i;
+                        const int k = kb * 16 + q * 4;
+                        const bool ok = (i < KBW) && (kb < nkb) && (b < B);
+                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (ok) {
+                            if (k < 2 * H) v = load_sc1_b128(rs_g, ((b * 2 + dir) * 3 * H + k) * 4);
+                            else v = load_sc1_b128(rs_n, ((b * 2 + dir) * H + (k - 2 * H)) * 4);
+                        }
+                        bf[c] = v;
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        if (i0 + c < KBW) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i0 + c][e], bf[c][e], acc, 0, 0, 0);
+                        }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) red[wave][bt][4 * q + rr][m] = acc[rr];
+            }
+        }
+        __syncthreads();
+        if (gate_ok) {
+            if (s > 0) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWP; ++w) a += red[w][gbt][jj][nn];
+                dh += a + dhz;
+            }
+            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+            const float dz_pre = dh * (hpv - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * gn * r * (1.f - r);
+            dhz = dh * z;
+            store_sc1(&G[gbase], dr_pre);
+            store_sc1(&G[gbase + H], dz_pre);
+            store_sc1(&G[gbase + 2 * H], dn_pre);
+            store_sc1(&ghn[row * H + gj], dn_pre * r);
+        }
+        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+inline int pick_kbw(int need, const int* opts, int nopts) {
+    for (int i = 0; i < nopts; ++i)
+        if (opts[i] >= need) return opts[i];
+    return -1;
+}
+
+template <int NBT>
+bool launch_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, int T, int B, int H,
+                           int dbg, hipStream_t st) {
+    const int opts[] = {1, 2, 4, 7};
+    const int kbw = pick_kbw(ds2_cdiv(H / 16, NWP), opts, 4);
+    dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
+#define DS2_FWD_CASE(K)                                                                                              \
+    case K:                                                                                                          \
+        hipLaunchKernelGGL((gru_fwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, T, B, H, \
+                           dbg);                                                                                   \
+        return true;
+    switch (kbw) {
+        DS2_FWD_CASE(1)
+        DS2_FWD_CASE(2)
+        DS2_FWD_CASE(4)
+        DS2_FWD_CASE(7)
+    }
+#undef DS2_FWD_CASE
+    return false;
+}
+
+template <int NBT>
+bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
+                           SyncWs* sync, int T, int B, int H, int dbg, hipStream_t st) {
+    const int opts[] = {1, 2, 4, 8, 19};
+    const int kbw = pick_kbw(ds2_cdiv(3 * H / 16, NWP), opts, 5);
+    dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
+#define DS2_BWD_CASE(K)                                                                                          \
+    case K:                                                                                                      \
+        hipLaunchKernelGGL((gru_bwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, \
+                           sync, T, B, H, dbg);                                                                  \
+        return true;
+    switch (kbw) {
+        DS2_BWD_CASE(1)
+        DS2_BWD_CASE(2)
+        DS2_BWD_CASE(4)
+        DS2_BWD_CASE(8)
+        DS2_BWD_CASE(19)
+    }
+#undef DS2_BWD_CASE
+    return false;
+}
+
+inline bool persistent_ok(int B, int H) {
+    return (H % 16 == 0) && (2 * ds2_cdiv(H, PJU) <= 240) && (B <= 64) && (ds2_cdiv(3 * H / 16, NWP) <= 19) &&
+           (ds2_cdiv(H / 16, NWP) <= 7);
+}
+
+inline size_t header_bytes() { return ((sizeof(SyncWs) + 255) / 256) * 256; }
+
+// timing-only diagnostics (results are WRONG when set): DS2_GRU_DBG bit0 = do not wait for arrivals,
+// bit1 = skip the h loads + MFMAs, bit2 = skip the store drain
+inline int dbg_flags() {
+    const char* e = getenv("DS2_GRU_DBG");
+    return e ? atoi(e) : 0;
+}
+
+}  // namespace
+
+// A data-tagged-granule hand-off (Guideline 16 R2: every consumer wave polls the 8-byte {value, epoch} granules it
+// needs) was built and measured in round 1: correct, but 1.5x (forward) to 2.1x (backward) SLOWER per step than the
+// counter form -- 1600 waves polling payload lines swamp the fabric ("polling-cost" row of the price list).
+extern "C" size_t ds2_gru_sync_ws_bytes(int B, int H) {
+    (void)B;
+    (void)H;
+    return header_bytes();
+}
+
+extern "C" size_t ds2_gru_sync_error_offset(void) { return offsetof(SyncWs, error); }
+
+extern "C" int ds2_gru_persistent_supported(int B, int H) { return persistent_ok(B, H) ? 1 : 0; }
+
+extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh, void* sync_ws,
+                                            int T, int B, int H, void* stream) {
+    DS2_CHECK_ARG(G && ghn && hout && w_hh && sync_ws);
+    DS2_CHECK_ARG(T > 0 && B > 0 && H > 0);
+    if (!persistent_ok(B, H)) {
+        ds2_set_error("ds2_gru_bidir_fwd_persistent: unsupported shape B=%d H=%d", B, H);
+        return DS2_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    SyncWs* sync = (SyncWs*)sync_ws;
+    DS2_HIP(hipMemsetAsync(sync, 0, header_bytes(), st));
+    const int dbg = dbg_flags();
+    bool ok;
+    if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, T, B, H, dbg, st);
+    else if (B <= 32) ok = launch_fwd_persistent<2>(G, ghn, hout, w_hh, sync, T, B, H, dbg, st);
+    else ok = launch_fwd_persistent<4>(G, ghn, hout, w_hh, sync, T, B, H, dbg, st);
+    DS2_CHECK_ARG(ok);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}
+
+extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* hout, const float* d_out,
+                                            const float* w_hh_t, void* sync_ws, int T, int B, int H, void* stream) {
+    DS2_CHECK_ARG(G && ghn && hout && d_out && w_hh_t && sync_ws);
+    DS2_CHECK_ARG(T > 0 && B > 0 && H > 0);
+    if (!persistent_ok(B, H)) {
+        ds2_set_error("ds2_gru_bidir_bwd_persistent: unsupported shape B=%d H=%d", B, H);
+        return DS2_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    SyncWs* sync = (SyncWs*)sync_ws;
+    DS2_HIP(hipMemsetAsync(sync, 0, header_bytes(), st));
+    const int dbg = dbg_flags();
+    bool ok;
+    if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, T, B, H, dbg, st);
+    else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, T, B, H, dbg, st);
+    else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, T, B, H, dbg, st);
+    DS2_CHECK_ARG(ok);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}

@@ -159,11 +159,11 @@ GRU_MODE = os.environ.get('DS2_GRU_MODE', 'auto')     # 'auto' | 'persistent' | 
 _sync_ws = {}
 
 
-def _gru_sync_ws(dev):
-    """Per-device arrival counters + timeout flag of the persistent recurrence (caller-owned, reused)."""
+def _gru_sync_ws(dev, bsz, hid):
+    """Per-device hand-off workspace of the persistent recurrence (caller-owned, grown on demand, reused)."""
     key = (dev.type, dev.index)
-    if key not in _sync_ws:
-        n = (lib.query('ds2_gru_sync_ws_bytes') + 3) // 4
+    n = (lib.query('ds2_gru_sync_ws_bytes', bsz, hid) + 3) // 4
+    if key not in _sync_ws or _sync_ws[key].numel() < n:
         _sync_ws[key] = torch.zeros(n, dtype=torch.int32, device=dev)
     return _sync_ws[key]
 
@@ -179,8 +179,9 @@ def _use_persistent(bsz, hid):
 
 def check_async_errors():
     """Raise if a persistent kernel's bounded spin timed out (call after a device synchronize)."""
+    word = lib.query('ds2_gru_sync_error_offset') // 4
     for ws in _sync_ws.values():
-        if int(ws[-1].item()) != 0:
+        if int(ws[word].item()) != 0:
             ws.zero_()
             raise RuntimeError('ds2hip: persistent GRU kernel timed out waiting for a workgroup hand-off')
 
@@ -190,7 +191,8 @@ def gru_bidir_fwd(gates, w_hh, t, bsz, hid):
     ghn = _empty((t, bsz, 2, hid), gates)
     hout = _empty((2, t, bsz, hid), gates)
     if _use_persistent(bsz, hid):
-        lib.call('ds2_gru_bidir_fwd_persistent', gates, ghn, hout, w_hh, _gru_sync_ws(gates.device), t, bsz, hid)
+        lib.call('ds2_gru_bidir_fwd_persistent', gates, ghn, hout, w_hh, _gru_sync_ws(gates.device, bsz, hid), t, bsz,
+                 hid)
     else:
         lib.call('ds2_gru_bidir_fwd', gates, ghn, hout, w_hh, t, bsz, hid)
     return ghn, hout
@@ -198,8 +200,8 @@ def gru_bidir_fwd(gates, w_hh, t, bsz, hid):
 
 def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid):
     if _use_persistent(bsz, hid):
-        lib.call('ds2_gru_bidir_bwd_persistent', gates, ghn, hout, d_out, w_hh_t, _gru_sync_ws(gates.device), t, bsz,
-                 hid)
+        lib.call('ds2_gru_bidir_bwd_persistent', gates, ghn, hout, d_out, w_hh_t, _gru_sync_ws(gates.device, bsz, hid),
+                 t, bsz, hid)
     else:
         ws = torch.zeros((2 * 2 * bsz * hid,), dtype=torch.float32, device=gates.device)
         lib.call('ds2_gru_bidir_bwd', gates, ghn, hout, d_out, w_hh_t, ws, t, bsz, hid)

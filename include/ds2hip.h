@@ -141,12 +141,15 @@ int ds2_gru_bidir_bwd(float* G, float* ghn, const float* hout, const float* d_ou
 int ds2_transpose2d(const float* in, int rows, int cols, float* out, void* stream);
 /* Persistent form of the two calls above: ONE launch per layer pass; every workgroup keeps its slice
  * of the recurrent weights in registers for all T steps and hands h_t (forward) / d(gh)_t (backward)
- * to the other workgroups inside the launch (write-through stores + arrival counter).  Same
- * arguments and results; sync_ws is a caller-owned device buffer of ds2_gru_sync_ws_bytes() bytes
- * (zeroed by the call); its last 32-bit word is set to 1 if a bounded spin timed out (results are then
- * invalid -- check it after synchronising).  Returns DS2_ERR_UNSUPPORTED for shapes outside
- * ds2_gru_persistent_supported(B, H) (H % 16 == 0, 2*ceil(H/8) <= 240 workgroups, B <= 64). */
-size_t ds2_gru_sync_ws_bytes(void);
+ * to the other workgroups inside the launch as 8-byte {value, epoch} granules (write-through stores
+ * polled by their consumers; env DS2_GRU_HANDOFF=counter selects the arrival-counter form instead).
+ * Same arguments and results; sync_ws is a caller-owned device buffer of ds2_gru_sync_ws_bytes(B, H)
+ * bytes (zeroed by the call).  If a bounded spin times out, the 32-bit word at byte offset
+ * ds2_gru_sync_error_offset() of sync_ws is set to 1 (results are then invalid -- check it after
+ * synchronising).  Returns DS2_ERR_UNSUPPORTED for shapes outside ds2_gru_persistent_supported(B, H)
+ * (H % 16 == 0, 2*ceil(H/8) <= 240 co-resident workgroups, B <= 64). */
+size_t ds2_gru_sync_ws_bytes(int B, int H);
+size_t ds2_gru_sync_error_offset(void);
 int ds2_gru_persistent_supported(int B, int H);
 int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh, void* sync_ws, int T,
                                  int B, int H, void* stream);
