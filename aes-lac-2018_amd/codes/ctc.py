@@ -14,23 +14,27 @@ import torch
 from ds2hip import ops
 
 
-def _dev_i32(x, dev):
-    return torch.as_tensor(x).to(device=dev, dtype=torch.int32).contiguous()
-
-
 def ctc_costs_and_grad(acts, labels, act_lens, label_lens, grad_scale=1.0):
-    """Raw kernel call: returns (costs (B,), grad (T,B,A)) on the device of ``acts``."""
+    """Raw kernel call: returns (costs (B,), grad (T,B,A)) on the device of ``acts``.
+
+    The four small integer arrays the warp-ctc signature passes on the host (labels, lengths) travel to the
+    device in ONE pinned upload."""
     dev = acts.device
-    label_lens_c = torch.as_tensor(label_lens).to('cpu', torch.int64)
-    max_len = int(label_lens_c.max().item()) if label_lens_c.numel() else 0
-    offsets = torch.zeros_like(label_lens_c)
-    if label_lens_c.numel() > 1:
-        offsets[1:] = torch.cumsum(label_lens_c, 0)[:-1]
-    labels_d = _dev_i32(labels, dev).reshape(-1)
-    if labels_d.numel() == 0:
-        labels_d = torch.zeros(1, dtype=torch.int32, device=dev)
-    return ops.ctc_loss_grad(acts.contiguous().float(), labels_d, _dev_i32(offsets, dev),
-                             _dev_i32(label_lens_c, dev), _dev_i32(act_lens, dev), max_len, grad_scale)
+    label_lens_c = torch.as_tensor(label_lens).to('cpu', torch.int32).reshape(-1)
+    act_lens_c = torch.as_tensor(act_lens).to('cpu', torch.int32).reshape(-1)
+    labels_c = torch.as_tensor(labels).to('cpu', torch.int32).reshape(-1)
+    bsz = label_lens_c.numel()
+    max_len = int(label_lens_c.max().item()) if bsz else 0
+    nlab = max(int(labels_c.numel()), 1)
+    packed = torch.zeros(nlab + 3 * bsz, dtype=torch.int32).pin_memory()
+    packed[:labels_c.numel()] = labels_c
+    if bsz > 1:
+        packed[nlab + 1:nlab + bsz] = torch.cumsum(label_lens_c, 0)[:-1]          # start of each utterance's labels
+    packed[nlab + bsz:nlab + 2 * bsz] = label_lens_c
+    packed[nlab + 2 * bsz:] = act_lens_c
+    d = packed.to(dev, non_blocking=True)
+    return ops.ctc_loss_grad(acts.contiguous().float(), d[:nlab], d[nlab:nlab + bsz], d[nlab + bsz:nlab + 2 * bsz],
+                             d[nlab + 2 * bsz:], max_len, grad_scale)
 
 
 class _CTCFunction(torch.autograd.Function):

@@ -123,12 +123,16 @@ class Trainer(object):
         ops.clip_sgd_nesterov(model._flat_p, gflat, self._buf, self._sumsq, scale, self.max_norm, g['lr'],
                               g['momentum'], self._first)
         self._first = False
-        loss = costs.sum() / bsz
+        # one device->host readback for everything the host needs: loss, grad norm^2, kernel timeout flags
+        words = ops.async_error_words()
+        stats = torch.cat([costs.sum().double().reshape(1) / bsz, self._sumsq] + [w.double() for w in words])
         torch.cuda.synchronize()                                          # codes/engine.py:92
-        ops.check_async_errors()
+        stats = stats.tolist()
+        if any(v != 0 for v in stats[2:]):
+            ops.raise_async_error()
         self.iteration += 1
-        loss_v = float(loss.item())
-        self.last_grad_norm = float(self._sumsq.item()) ** 0.5 * scale
+        loss_v = float(stats[0])
+        self.last_grad_norm = float(stats[1]) ** 0.5 * scale
         if loss_v in (float('inf'), float('-inf')):
             LOG.warning('WARNING: received an inf loss, setting loss value to 0')   # codes/engine.py:27-30
             loss_v = 0.0

@@ -62,23 +62,41 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < NT; ++i) tbase[i] = ST * (t0 + 32 * i + lr) - PADT + lh;
 
+    // rows r = (ci, kf) of the filter, walked with a one-row register prefetch: the 6 weight pairs and
+    // 6*NT input pairs of row r+1 are in flight while the 6*NT MFMAs of row r issue.
+    constexpr int NROWS = CIN * KF;
     const float* wp = wt + lh * 32 + lr;
-    for (int ci = 0; ci < CIN; ++ci) {
-        const float* rowbase = in + (((size_t)b * CIN + ci) * FIN + (size_t)SF * d) * TIN;
-        for (int kf = 0; kf < KF; ++kf) {
-            const float* row = rowbase + (size_t)kf * TIN;
+    const float* inb = in + ((size_t)b * CIN * FIN + (size_t)SF * d) * TIN;
+    float a_nxt[KTP / 2], v_nxt[NT][KTP / 2];
+    auto fetch = [&](int r) {
+        const int ci = r / KF, kf = r - ci * KF;
+        const float* row = inb + ((size_t)ci * FIN + kf) * TIN;
+        const float* w = wp + (size_t)r * (KTP * 32);
 #pragma unroll
-            for (int kp = 0; kp < KTP / 2; ++kp) {
-                const float a = wp[kp * 64];
+        for (int kp = 0; kp < KTP / 2; ++kp) {
+            a_nxt[kp] = w[kp * 64];
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int ti = tbase[i] + 2 * kp;
-                    const float v = (ti >= 0 && ti < TIN) ? row[ti] : 0.f;
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[i], 0, 0, 0);
-                }
+            for (int i = 0; i < NT; ++i) {
+                const int ti = tbase[i] + 2 * kp;
+                v_nxt[i][kp] = (ti >= 0 && ti < TIN) ? row[ti] : 0.f;
             }
-            wp += KTP * 32;
         }
+    };
+    fetch(0);
+    for (int r = 0; r < NROWS; ++r) {
+        float a_cur[KTP / 2], v_cur[NT][KTP / 2];
+#pragma unroll
+        for (int kp = 0; kp < KTP / 2; ++kp) {
+            a_cur[kp] = a_nxt[kp];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) v_cur[i][kp] = v_nxt[i][kp];
+        }
+        if (r + 1 < NROWS) fetch(r + 1);
+#pragma unroll
+        for (int kp = 0; kp < KTP / 2; ++kp)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[kp], v_cur[i][kp], acc[i], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -118,23 +136,42 @@ __global__ __launch_bounds__(256) void conv2_dgrad_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < NT; ++i) tbase[i] = t0 + 32 * i + lr - lh;
 
-    for (int co = 0; co < 32; ++co) {
-        for (int kf = (f & 1); kf < KF; kf += 2) {
-            const int d = (f - kf) >> 1;
-            if (d < 0 || d >= FOUT) continue;
-            const float* row = dout + (((size_t)b * 32 + co) * FOUT + d) * T;
-            const float* wp = wd + ((size_t)(co * KF + kf) * KTP) * 32 + lh * 32 + lr;
+    // valid filter rows for this input row f: kf = f (mod 2) with 0 <= (f-kf)/2 < FOUT
+    const int kf_first = max(f & 1, f - 2 * (FOUT - 1));
+    int nkf = 0;
+    for (int kf = kf_first; kf < KF && kf <= f; kf += 2) ++nkf;
+    const int nrows = 32 * nkf;
+    float a_nxt[KTP / 2], v_nxt[NT][KTP / 2];
+    auto fetch = [&](int r) {
+        const int co = r / nkf, kf = kf_first + 2 * (r - co * nkf);
+        const int d = (f - kf) >> 1;
+        const float* row = dout + (((size_t)b * 32 + co) * FOUT + d) * T;
+        const float* w = wd + ((size_t)(co * KF + kf) * KTP) * 32 + lh * 32 + lr;
 #pragma unroll
-            for (int kp = 0; kp < KTP / 2; ++kp) {
-                const float a = wp[kp * 64];
+        for (int kp = 0; kp < KTP / 2; ++kp) {
+            a_nxt[kp] = w[kp * 64];
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int ti = tbase[i] - 2 * kp;
-                    const float v = (ti >= 0 && ti < T) ? row[ti] : 0.f;
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc[i], 0, 0, 0);
-                }
+            for (int i = 0; i < NT; ++i) {
+                const int ti = tbase[i] - 2 * kp;
+                v_nxt[i][kp] = (ti >= 0 && ti < T) ? row[ti] : 0.f;
             }
         }
+    };
+    if (nrows > 0) fetch(0);
+    for (int r = 0; r < nrows; ++r) {
+        float a_cur[KTP / 2], v_cur[NT][KTP / 2];
+#pragma unroll
+        for (int kp = 0; kp < KTP / 2; ++kp) {
+            a_cur[kp] = a_nxt[kp];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) v_cur[i][kp] = v_nxt[i][kp];
+        }
+        if (r + 1 < nrows) fetch(r + 1);
+#pragma unroll
+        for (int kp = 0; kp < KTP / 2; ++kp)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[kp], v_cur[i][kp], acc[i], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -174,17 +211,52 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
         const int b = row / FOUT, d = row % FOUT;
         const float* ap = dout + (((size_t)b * 32 + lr) * FOUT + d) * TOUT;
         const float* bp = in + (((size_t)b * CIN + ci) * FIN + (size_t)SF * d + kf) * TIN;
-        for (int t0 = 0; t0 < TOUT; t0 += 8) {
-            const int t = t0 + 4 * lh;
-            float a[4], v[4];
+        // 16 time steps per iteration: half-wave lh owns steps [t0 + 8 lh, t0 + 8 lh + 8) for A and B alike
+        // (the k order inside the MFMA chain is free as long as both operands agree); the next group's
+        // operands are fetched (two unaligned dwordx4 per operand) while the 8 MFMAs of this one issue.
+        float a_nxt[8], v_nxt[8];
+        auto fetch = [&](int t0) {
+            const int t = t0 + 8 * lh;
+            if (t + 7 < TOUT) {
+                const f32x4u x0 = *reinterpret_cast<const f32x4u*>(ap + t);
+                const f32x4u x1 = *reinterpret_cast<const f32x4u*>(ap + t + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a[e] = (t + e < TOUT) ? ap[t + e] : 0.f;
-                const int ti = ST * (t + e) + kt - PADT;
-                v[e] = (n_ok && t + e < TOUT && ti >= 0 && ti < TIN) ? bp[ti] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    a_nxt[e] = x0[e];
+                    a_nxt[4 + e] = x1[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a_nxt[e] = (t + e < TOUT) ? ap[t + e] : 0.f;
             }
+            const int ti0 = ST * t + kt - PADT;
+            if (ST == 1 && n_ok && t + 7 < TOUT && ti0 >= 0 && ti0 + 7 < TIN) {
+                const f32x4u y0 = *reinterpret_cast<const f32x4u*>(bp + ti0);
+                const f32x4u y1 = *reinterpret_cast<const f32x4u*>(bp + ti0 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; ++e) {
+                    v_nxt[e] = y0[e];
+                    v_nxt[4 + e] = y1[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ti = ti0 + ST * e;
+                    v_nxt[e] = (n_ok && t + e < TOUT && ti >= 0 && ti < TIN) ? bp[ti] : 0.f;
+                }
+            }
+        };
+        fetch(0);
+        for (int t0 = 0; t0 < TOUT; t0 += 16) {
+            float a[8], v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a[e] = a_nxt[e];
+                v[e] = v_nxt[e];
+            }
+            if (t0 + 16 < TOUT) fetch(t0 + 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], v[e], acc, 0, 0, 0);
                 bsum += a[e];
             }

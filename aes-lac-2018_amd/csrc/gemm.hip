@@ -16,17 +16,18 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int NI = BK / 8;  // float4 per thread per operand slab
 constexpr int LDT = 132;  // LDS row pitch (floats): 16-B aligned rows, 2-way conflict at worst on writes
 
 // Stage one operand slab [BK][128] into registers.  KCONTIG: the source is X x K (x = m or n).
 template <bool KCONTIG, bool VEC>
 __device__ __forceinline__ void load_slab(const float* __restrict__ src, int ld, int x0, int xmax, int k0,
-                                          int kmax, int tid, f32x4 (&r)[2]) {
+                                          int kmax, int tid, f32x4 (&r)[NI]) {
     if (KCONTIG) {
-        const int kq = (tid & 3) * 4;
+        const int kq = (tid & (BK / 4 - 1)) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int x = x0 + (tid >> 2) + 64 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int x = x0 + tid / (BK / 4) + (1024 / BK) * i;
             const int k = k0 + kq;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (x < xmax) {
@@ -45,7 +46,7 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ src, int ld,
     } else {
         const int xq = (tid & 31) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int k = k0 + (tid >> 5) + 8 * i;
             const int x = x0 + xq;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -66,19 +67,19 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ src, int ld,
 }
 
 template <bool KCONTIG>
-__device__ __forceinline__ void store_slab(float* __restrict__ lds, int tid, const f32x4 (&r)[2]) {
+__device__ __forceinline__ void store_slab(float* __restrict__ lds, int tid, const f32x4 (&r)[NI]) {
     if (KCONTIG) {
-        const int kq = (tid & 3) * 4;
+        const int kq = (tid & (BK / 4 - 1)) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int x = (tid >> 2) + 64 * i;
+        for (int i = 0; i < NI; ++i) {
+            const int x = tid / (BK / 4) + (1024 / BK) * i;
 #pragma unroll
             for (int c = 0; c < 4; ++c) lds[(kq + c) * LDT + x] = r[i][c];
         }
     } else {
         const int xq = (tid & 31) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int k = (tid >> 5) + 8 * i;
             *reinterpret_cast<f32x4*>(&lds[k * LDT + xq]) = r[i];
         }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[2], rb[2];
+    f32x4 ra[NI], rb[NI];
     const int nslab = (kend - kbeg + BK - 1) / BK;
     if (nslab > 0) {
         load_slab<A_KCONTIG, VEC>(A, lda, m0, M, kbeg, kend, tid, ra);
@@ -172,13 +173,16 @@ template <bool AK, bool BKc>
 int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float beta,
            int split_k, hipStream_t st) {
     const int tm = ds2_cdiv(M, BM), tn = ds2_cdiv(N, BN);
-    if (split_k == 0) {  // auto: fill the 256 CUs (2 workgroups each) when the output grid alone cannot
+    if (split_k == 0) {  // auto: when M*N alone cannot fill the chip, split K so that ONE round of workgroups
+                         // (256 CUs x 4 resident 256-thread workgroups) is as full as possible
         const int tiles = tm * tn;
+        constexpr int kSlots = 1024;
         split_k = 1;
-        if (tiles < 384 && K >= 512) {
-            split_k = ds2_cdiv(512, tiles);
-            const int max_split = K / 256 > 1 ? K / 256 : 1;
+        if (tiles < kSlots / 2 && K >= 512) {
+            split_k = kSlots / tiles;
+            const int max_split = K / 128 > 1 ? K / 128 : 1;
             if (split_k > max_split) split_k = max_split;
+            if (split_k > 32) split_k = 32;
         }
     }
     if (split_k < 1) split_k = 1;

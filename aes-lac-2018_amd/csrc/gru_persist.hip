@@ -24,7 +24,9 @@ namespace {
 
 constexpr int NWP = 8;                    // waves per persistent workgroup (2 per SIMD)
 constexpr int PJU = 8;                    // hidden units per workgroup
-constexpr unsigned long long SPIN_TICKS = 50000000ull;  // 0.5 s of the 100 MHz real-time counter
+constexpr unsigned long long SPIN_TICKS = 500000000ull;  // 5 s of the 100 MHz real-time counter: long enough to
+                                                         // sit out a peer workgroup that is waiting for CUs held by
+                                                         // a concurrent RCCL kernel, short enough to end a lost run
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

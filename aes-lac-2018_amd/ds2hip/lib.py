@@ -90,12 +90,18 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+_fn_cache = {}
+
+
 def call(name, *args):
     """Invoke an int-returning entry point on the current torch stream; raise on error."""
-    lib = load()
-    rc = getattr(lib, name)(*[_ptr(a) for a in args], stream_ptr())
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
+    rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) and a.is_cuda and a.is_contiguous() else _ptr(a)
+              for a in args], torch.cuda.current_stream().cuda_stream)
     if rc != 0:
-        raise RuntimeError('%s failed (%d): %s' % (name, rc, lib.ds2_last_error().decode()))
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, load().ds2_last_error().decode()))
 
 
 def query(name, *args):

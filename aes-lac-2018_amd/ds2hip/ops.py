@@ -177,13 +177,23 @@ def _use_persistent(bsz, hid):
     return ok
 
 
+def async_error_words():
+    """Device views of the timeout flags of the persistent recurrence (one int32 per device workspace)."""
+    word = lib.query('ds2_gru_sync_error_offset') // 4
+    return [ws[word:word + 1] for ws in _sync_ws.values()]
+
+
+def raise_async_error():
+    for ws in _sync_ws.values():
+        ws.zero_()
+    raise RuntimeError('ds2hip: persistent GRU kernel timed out waiting for a workgroup hand-off')
+
+
 def check_async_errors():
     """Raise if a persistent kernel's bounded spin timed out (call after a device synchronize)."""
-    word = lib.query('ds2_gru_sync_error_offset') // 4
-    for ws in _sync_ws.values():
-        if int(ws[word].item()) != 0:
-            ws.zero_()
-            raise RuntimeError('ds2hip: persistent GRU kernel timed out waiting for a workgroup hand-off')
+    for w in async_error_words():
+        if int(w.item()) != 0:
+            raise_async_error()
 
 
 def gru_bidir_fwd(gates, w_hh, t, bsz, hid):

@@ -35,8 +35,12 @@ HOP = 160
 NUM_BINS = 24
 
 
-def synth_bins(batch_size, num_bins, seed=42, nalpha=29):
-    """SURVEY.md 8(d) synthetic corpus: returns a list of bins [(wavs list, labels, label_lens)]."""
+def synth_bins(batch_size, num_bins, seed=42, nalpha=29, world=1):
+    """SURVEY.md 8(d) synthetic corpus: returns a list of bins [(wavs list, labels, label_lens)].
+
+    Bins are length-sorted; groups of `world` ADJACENT bins are then shuffled as units, so that bins
+    i*world .. i*world+world-1 (the ones the `world` ranks consume in the same step under the
+    every-world-th rule) hold clips of similar length (minimises straggling)."""
     rng = np.random.default_rng(seed)
     n = batch_size * num_bins
     dur = np.sort(rng.uniform(1.0, 15.0, size=n))
@@ -50,8 +54,8 @@ def synth_bins(batch_size, num_bins, seed=42, nalpha=29):
             labels.append(rng.integers(1, nalpha, size=ll).astype(np.int32))
             lens.append(ll)
         bins.append((wavs, np.concatenate(labels), np.asarray(lens, np.int32)))
-    order = np.random.default_rng(seed + 1).permutation(num_bins)   # epoch-2-style shuffled bins
-    return [bins[i] for i in order]
+    groups = np.random.default_rng(seed + 1).permutation(num_bins // world)   # epoch-2-style shuffled bins
+    return [bins[g * world + r] for g in groups for r in range(world)]
 
 
 def frames_of(bin_):
@@ -161,7 +165,7 @@ def main():
     from codes.transforms import BatchSpectrogram
 
     bsz = args.batch_size
-    bins = synth_bins(bsz, NUM_BINS * world)
+    bins = synth_bins(bsz, NUM_BINS * world, world=world)
     mine = bins[rank::world]                                             # every world-th bin, starting from rank
     dev = torch.device('cuda', local)
     resident = []
