@@ -124,28 +124,36 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             const float* hprev = hout + ((size_t)dir * T + tprev) * B * H;
             const __amdgpu_buffer_rsrc_t rsrc =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hprev), 0, B * H * 4, 0x00020000);
-#pragma unroll 1
-            for (int bt = 0; bt < ((dbg & 2) ? 0 : NBT); ++bt) {
+            // batch tiles are software-pipelined: the h fragments of tile bt+1 are in flight while the MFMAs of
+            // tile bt issue (fully unrolled so the two fragment buffers stay in registers)
+            f32x4 bf[2][KBW];
+            auto fetch = [&](int bt, f32x4 (&dst)[KBW]) {
                 const int b = bt * 16 + m;
-                f32x4 bf[KBW];
 #pragma unroll
                 for (int i = 0; i < KBW; ++i) {
                     const int kb = wave + NWP * i;
                     const bool ok = (kb < nkb) && (b < B);
-                    bf[i] = ok ? load_sc1_b128(rsrc, (b * H + kb * 16 + q * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    dst[i] = ok ? load_sc1_b128(rsrc, (b * H + kb * 16 + q * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            };
+            if (!(dbg & 2)) {
+                fetch(0, bf[0]);
 #pragma unroll
-                for (int i = 0; i < KBW; ++i)
+                for (int bt = 0; bt < NBT; ++bt) {
+                    if (bt + 1 < NBT) fetch(bt + 1, bf[(bt + 1) & 1]);
+                    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][i][e], bf[i][e], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[1][i][e], bf[i][e], acc1, 0, 0, 0);
+                    for (int i = 0; i < KBW; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][i][e], bf[bt & 1][i][e], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[1][i][e], bf[bt & 1][i][e], acc1, 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        red[wave][0][bt][4 * q + r][m] = acc0[r];
+                        red[wave][1][bt][4 * q + r][m] = acc1[r];
                     }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    red[wave][0][bt][4 * q + r][m] = acc0[r];
-                    red[wave][1][bt][4 * q + r][m] = acc1[r];
                 }
             }
         }
@@ -239,38 +247,48 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
                 G + (size_t)tnext * B * 6 * H, 0, B * 6 * H * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
                 ghn + (size_t)tnext * B * 2 * H, 0, B * 2 * H * 4, 0x00020000);
-#pragma unroll 1
-            for (int bt = 0; bt < ((dbg & 2) ? 0 : NBT); ++bt) {
+            // stages = (batch tile, k chunk); the fragments of stage st+1 are fetched while stage st's MFMAs issue
+            constexpr int CH = (NBT > 1 && KBW > 10) ? 7 : KBW;
+            constexpr int NCH = (KBW + CH - 1) / CH;
+            constexpr int NST = NBT * NCH;
+            f32x4 bf[2][CH];
+            auto fetch = [&](int st, f32x4 (&dst)[CH]) {
+                const int bt = st / NCH, i0 = (st % NCH) * CH;
                 const int b = bt * 16 + m;
-                // with several batch tiles the fragments are fetched in chunks to stay inside 256 VGPRs
-                constexpr int CH = (NBT > 1 && KBW > 10) ? 10 : KBW;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int i = i0 + c;
+                    const int kb = wave + NWP * i;
+                    const int k = kb * 16 + q * 4;
+                    const bool ok = (i < KBW) && (kb < nkb) && (b < B);
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok) {
+                        if (k < 2 * H) v = load_sc1_b128(rs_g, ((b * 2 + dir) * 3 * H + k) * 4);
+                        else v = load_sc1_b128(rs_n, ((b * 2 + dir) * H + (k - 2 * H)) * 4);
+                    }
+                    dst[c] = v;
+                }
+            };
+            if (!(dbg & 2)) {
+                fetch(0, bf[0]);
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i0 = 0; i0 < KBW; i0 += CH) {
-                    f32x4 bf[CH];
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const int i = i0 + c;
-                        const int kb = wave + NWP * i;
-                        const int k = kb * 16 + q * 4;
-                        const bool ok = (i < KBW) && (kb < nkb) && (b < B);
-                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (ok) {
-                            if (k < 2 * H) v = load_sc1_b128(rs_g, ((b * 2 + dir) * 3 * H + k) * 4);
-                            else v = load_sc1_b128(rs_n, ((b * 2 + dir) * H + (k - 2 * H)) * 4);
-                        }
-                        bf[c] = v;
-                    }
+                for (int st = 0; st < NST; ++st) {
+                    if (st + 1 < NST) fetch(st + 1, bf[(st + 1) & 1]);
+                    const int bt = st / NCH, i0 = (st % NCH) * CH;
 #pragma unroll
                     for (int c = 0; c < CH; ++c)
                         if (i0 + c < KBW) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i0 + c][e], bf[c][e], acc, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i0 + c][e], bf[st & 1][c][e], acc, 0, 0, 0);
                         }
-                }
+                    if ((st % NCH) == NCH - 1) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) red[wave][bt][4 * q + rr][m] = acc[rr];
+                        for (int rr = 0; rr < 4; ++rr) red[wave][bt][4 * q + rr][m] = acc[rr];
+                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
             }
         }
         __syncthreads();
