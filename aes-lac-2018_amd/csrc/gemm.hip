@@ -97,7 +97,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, c
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b and b+8 share an L2.
+    // Give every XCD a contiguous run of tiles (neighbours share an A panel) -- bijective for any tile count.
+    int tile;
+    {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int qd = nwg >> 3, rm = nwg & 7;
+        tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
     const int kbeg = blockIdx.y * k_per_split;

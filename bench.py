@@ -35,27 +35,36 @@ HOP = 160
 NUM_BINS = 24
 
 
-def synth_bins(batch_size, num_bins, seed=42, nalpha=29, world=1):
-    """SURVEY.md 8(d) synthetic corpus: returns a list of bins [(wavs list, labels, label_lens)].
+def bin_plan(batch_size, num_bins, seed=42, world=1):
+    """SURVEY.md 8(d) synthetic corpus, as a PLAN: a list of (bin_seed, durations[batch_size]).
 
-    Bins are length-sorted; groups of `world` ADJACENT bins are then shuffled as units, so that bins
-    i*world .. i*world+world-1 (the ones the `world` ranks consume in the same step under the
-    every-world-th rule) hold clips of similar length (minimises straggling)."""
+    Durations are uniform on [1 s, 15 s], sorted, cut into bins of batch_size (BucketingSampler).  Groups of `world`
+    ADJACENT bins are then shuffled as units, so that the bins the `world` ranks consume in the same step under the
+    every-world-th rule (codes/sampler.py:119-125) hold clips of similar length (minimises straggling).
+    Audio is only synthesised for the bins a process actually uses (make_bin)."""
     rng = np.random.default_rng(seed)
-    n = batch_size * num_bins
-    dur = np.sort(rng.uniform(1.0, 15.0, size=n))
-    bins = []
-    for i in range(num_bins):
-        wavs, labels, lens = [], [], []
-        for d in dur[i * batch_size:(i + 1) * batch_size]:
-            nsamp = int(round(d * 16000))
-            wavs.append(np.clip(0.1 * rng.standard_normal(nsamp), -1.0, 1.0).astype(np.float32))
-            ll = max(1, int(round(14.0 * d)))
-            labels.append(rng.integers(1, nalpha, size=ll).astype(np.int32))
-            lens.append(ll)
-        bins.append((wavs, np.concatenate(labels), np.asarray(lens, np.int32)))
+    dur = np.sort(rng.uniform(1.0, 15.0, size=batch_size * num_bins))
+    bins = [(seed * 100003 + i, dur[i * batch_size:(i + 1) * batch_size]) for i in range(num_bins)]
     groups = np.random.default_rng(seed + 1).permutation(num_bins // world)   # epoch-2-style shuffled bins
     return [bins[g * world + r] for g in groups for r in range(world)]
+
+
+def make_bin(plan_entry, nalpha=29):
+    """(wavs list, labels, label_lens): N(0, 0.1^2) audio clipped to [-1, 1], labels uniform on 1..A-1 at 14 chars/s."""
+    bin_seed, durations = plan_entry
+    rng = np.random.default_rng(bin_seed)
+    wavs, labels, lens = [], [], []
+    for d in durations:
+        nsamp = int(round(d * 16000))
+        wavs.append(np.clip(0.1 * rng.standard_normal(nsamp), -1.0, 1.0).astype(np.float32))
+        ll = max(1, int(round(14.0 * d)))
+        labels.append(rng.integers(1, nalpha, size=ll).astype(np.int32))
+        lens.append(ll)
+    return wavs, np.concatenate(labels), np.asarray(lens, np.int32)
+
+
+def frames_of_plan(plan_entry):
+    return int(sum(1 + int(round(d * 16000)) // HOP for d in plan_entry[1]))
 
 
 def frames_of(bin_):
@@ -67,7 +76,7 @@ def out_steps_of(bin_):
     return ((t_in + 9) // 2 - 9) * len(bin_[0])      # padded output steps actually computed
 
 
-def cpu_baseline(bins, budget_s=25.0):
+def cpu_baseline(plan, budget_s=25.0):
     """The oracle (stock PyTorch CPU ops, numerically the reference) timed on the host cores: one bounded
     training step (frontend -> fwd -> CTC -> bwd -> clip -> SGD) on the shortest bin(s)."""
     import torch.nn.functional as F
@@ -77,7 +86,8 @@ def cpu_baseline(bins, budget_s=25.0):
     model = OracleDeepSpeech()
     opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
     model.train()
-    order = sorted(range(len(bins)), key=lambda i: frames_of(bins[i]))
+    order = sorted(range(len(plan)), key=lambda i: frames_of_plan(plan[i]))
+    bins = {i: make_bin(plan[i]) for i in order[:3]}
     frames, secs, used = 0, 0.0, []
     for idx in order[:3]:
         wavs, labels, lens = bins[idx]
@@ -155,8 +165,12 @@ def main():
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X: the product path has no CPU fallback')
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('DS2_BENCH_FORCE_DIST') == '1'    # the latter: 1-rank RCCL group, for testing
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', init_method='env://')
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
@@ -165,8 +179,8 @@ def main():
     from codes.transforms import BatchSpectrogram
 
     bsz = args.batch_size
-    bins = synth_bins(bsz, NUM_BINS * world, world=world)
-    mine = bins[rank::world]                                             # every world-th bin, starting from rank
+    plan = bin_plan(bsz, NUM_BINS * world, world=world)
+    mine = [make_bin(p) for p in plan[rank::world]]                      # every world-th bin, starting from rank
     dev = torch.device('cuda', local)
     resident = []
     for wavs, labels, lens in mine:                                       # inputs resident in HBM before timing
@@ -187,28 +201,27 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     for i in range(args.warmup, args.warmup + args.steps):
         loss = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.time() - t0
     idxs = [i % len(mine) for i in range(args.warmup, args.warmup + args.steps)]
     frames = float(sum(frames_of(mine[i]) for i in idxs))
     osteps = float(sum(out_steps_of(mine[i]) for i in idxs))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt, frames, osteps], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, frames, osteps = float(tmax[0]), float(t[1]), float(t[2])
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     value = frames / dt
@@ -216,6 +229,13 @@ def main():
     t_mean = int(round(np.mean([out_steps_of(b) / len(b[0]) for b in mine])))
     roof = gru_pass_roofline(model, bsz, t_mean)
     ach, dur, flop = roof['bwd']
+    traffic = None                      # HBM bytes per launch from a committed rocprofv3 --pmc run of the same shape
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+        if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
+            traffic = rec['gru_bwd_persistent_kernel']['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
     result = {
         'metric': 'train frames/sec, DeepSpeech2 5xBiGRU-800',
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -230,7 +250,7 @@ def main():
                      'kernel': 'gru_bwd_persistent_kernel (one launch = all T=%d steps of a BiGRU layer, both '
                                'directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': None,
+                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic,
                      'avg_launch_us': round(dur * 1e6, 1), 'us_per_time_step': round(dur * 1e6 / t_mean, 3),
                      'flop_per_launch': flop,
                      'fwd_kernel_tflops': round(roof['fwd'][0], 3),
@@ -239,9 +259,9 @@ def main():
                      'whole_step_frac_of_f32_mfma_peak': round(step_tflops / PEAK_F32_MFMA_TFLOPS, 5)},
     }
     if not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(bins)
+        result['cpu_baseline'] = cpu_baseline(plan)
     print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
