@@ -26,6 +26,22 @@ __global__ void rate(float* out, int iters) {
     if (threadIdx.x == 0) out[64] = (float)(t1 - t0) / (4.0f * iters);
 }
 
+__global__ void rate12(float* out, int iters) {
+    f32x4 c[12];
+    for (int i = 0; i < 12; ++i) c[i] = f32x4{0, 0, 0, 0};
+    float a = threadIdx.x * 0.001f, b = 1.0f;
+    long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) c[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c[j], 0, 0, 0);
+    }
+    long long t1 = clock64();
+    float s = 0;
+    for (int j = 0; j < 12; ++j) s += c[j][j & 3];
+    out[threadIdx.x] = s;
+    if (threadIdx.x == 0) out[64] = (float)(t1 - t0) / (12.0f * iters);
+}
+
 __global__ void rate16(float* out, int iters) {
     f32x4 c0 = {0, 0, 0, 0}, c1 = c0;
     float a = threadIdx.x * 0.001f, b = 1.0f;
@@ -68,6 +84,14 @@ int main() {
     std::vector<float> ho(65);
     rate<<<1, 64>>>(o, 100000); hipMemcpy(ho.data(), o, 65 * 4, hipMemcpyDeviceToHost);
     printf("4x4x1_16b: %.2f clock64 ticks per instruction (1 wave)\n", ho[64]);
+    rate12<<<1, 64>>>(o, 100000); hipMemcpy(ho.data(), o, 65 * 4, hipMemcpyDeviceToHost);
+    printf("4x4x1_16b x12 accumulators: %.2f clock64 ticks per instruction (1 wave)\n", ho[64]);
+    rate12<<<1, 128>>>(o, 100000); hipMemcpy(ho.data(), o, 65 * 4, hipMemcpyDeviceToHost);
+    printf("4x4x1_16b x12 accumulators: %.2f ticks per instruction per wave (2 waves on the CU)\n", ho[64]);
+    rate12<<<1, 512>>>(o, 100000); hipMemcpy(ho.data(), o, 65 * 4, hipMemcpyDeviceToHost);
+    printf("4x4x1_16b x12 accumulators: %.2f ticks per instruction per wave (8 waves on the CU, 2 per SIMD)\n", ho[64]);
+    rate16<<<1, 512>>>(o, 100000); hipMemcpy(ho.data(), o, 65 * 4, hipMemcpyDeviceToHost);
+    printf("16x16x4  : %.2f ticks per instruction per wave (8 waves, 2 per SIMD)\n", ho[64]);
     rate16<<<1, 64>>>(o, 100000); hipMemcpy(ho.data(), o, 65 * 4, hipMemcpyDeviceToHost);
     printf("16x16x4  : %.2f clock64 ticks per instruction (1 wave)\n", ho[64]);
     return 0;
