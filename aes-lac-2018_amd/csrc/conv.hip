@@ -12,6 +12,8 @@
 // re-laid-out once per call into [.. k ..][32] so the A fetch is one coalesced 128-B read per
 // half-wave.  One wave = one 32 x (32*NT) output tile; 4 independent waves per workgroup walk
 // neighbouring frequency rows so their input windows overlap in L1/L2.
+#include <stdlib.h>
+
 #include "ds2_common.h"
 
 namespace {
@@ -41,7 +43,10 @@ template <int CIN, int KF, int SF, int ST, int PADT, int NT>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                        const float* __restrict__ bias, int B, int FIN, int TIN,
                                                        int FOUT, int TOUT, int ttiles, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // readfirstlane: lets hipcc see that everything derived from the wave id is wave-uniform (SGPR buffer
+    // descriptors instead of a waterfall loop per load -- cdna_hip_programming.md T20)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const long tile = (long)blockIdx.x * 4 + wave;
     const long ntiles = (long)B * ttiles * FOUT;
@@ -70,15 +75,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
     float a_nxt[KTP / 2], v_nxt[NT][KTP / 2];
     auto fetch = [&](int r) {
         const int ci = r / KF, kf = r - ci * KF;
-        const float* row = inb + ((size_t)ci * FIN + kf) * TIN;
+        // the input row as a buffer resource: out-of-range time steps (the conv padding, the ragged tile end)
+        // read back 0 from the hardware range check -- no compare, no select and, above all, no branch around
+        // the load (hipcc turns a guarded or selected load into a branch + vmcnt(0) per element)
+        const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(inb + ((size_t)ci * FIN + kf) * TIN), 0, TIN * 4, 0x00020000);
         const float* w = wp + (size_t)r * (KTP * 32);
 #pragma unroll
         for (int kp = 0; kp < KTP / 2; ++kp) {
             a_nxt[kp] = w[kp * 64];
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const int ti = tbase[i] + 2 * kp;
-                v_nxt[i][kp] = (ti >= 0 && ti < TIN) ? row[ti] : 0.f;
+                v_nxt[i][kp] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(row, (tbase[i] + 2 * kp) * 4, 0, 0));
             }
         }
     };
@@ -116,7 +125,10 @@ template <int KF, int NT>
 __global__ __launch_bounds__(256) void conv2_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ wd,
                                                           int B, int FIN, int T1, int FOUT, int T, int ttiles,
                                                           float* __restrict__ din) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // readfirstlane: lets hipcc see that everything derived from the wave id is wave-uniform (SGPR buffer
+    // descriptors instead of a waterfall loop per load -- cdna_hip_programming.md T20)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const long tile = (long)blockIdx.x * 4 + wave;
     const long ntiles = (long)B * ttiles * FIN;
@@ -145,15 +157,16 @@ __global__ __launch_bounds__(256) void conv2_dgrad_kernel(const float* __restric
     auto fetch = [&](int r) {
         const int co = r / nkf, kf = kf_first + 2 * (r - co * nkf);
         const int d = (f - kf) >> 1;
-        const float* row = dout + (((size_t)b * 32 + co) * FOUT + d) * T;
+        const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(dout + (((size_t)b * 32 + co) * FOUT + d) * T), 0, T * 4, 0x00020000);
         const float* w = wd + ((size_t)(co * KF + kf) * KTP) * 32 + lh * 32 + lr;
 #pragma unroll
         for (int kp = 0; kp < KTP / 2; ++kp) {
             a_nxt[kp] = w[kp * 64];
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const int ti = tbase[i] - 2 * kp;
-                v_nxt[i][kp] = (ti >= 0 && ti < T) ? row[ti] : 0.f;
+                v_nxt[i][kp] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(row, (tbase[i] - 2 * kp) * 4, 0, 0));
             }
         }
     };
@@ -194,7 +207,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
                                                          int B, int FIN, int TIN, int FOUT, int TOUT, int nsplit,
                                                          float* __restrict__ dw, float* __restrict__ dbias) {
     constexpr int NTOT = CIN * KF * KT;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // readfirstlane: lets hipcc see that everything derived from the wave id is wave-uniform (SGPR buffer
+    // descriptors instead of a waterfall loop per load -- cdna_hip_programming.md T20)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     const int n = blockIdx.x * 32 + lr;
     const bool n_ok = n < NTOT;
@@ -227,7 +243,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a_nxt[e] = (t + e < TOUT) ? ap[t + e] : 0.f;
+                for (int e = 0; e < 8; ++e) {
+                    const float x = ap[min(t + e, TOUT - 1)];
+                    a_nxt[e] = (t + e < TOUT) ? x : 0.f;
+                }
             }
             const int ti0 = ST * t + kt - PADT;
             if (ST == 1 && n_ok && t + 7 < TOUT && ti0 >= 0 && ti0 + 7 < TIN) {
@@ -242,7 +261,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int ti = ti0 + ST * e;
-                    v_nxt[e] = (n_ok && t + e < TOUT && ti >= 0 && ti < TIN) ? bp[ti] : 0.f;
+                    const float x = bp[min(max(ti, 0), TIN - 1)];
+                    v_nxt[e] = (n_ok && t + e < TOUT && ti >= 0 && ti < TIN) ? x : 0.f;
                 }
             }
         };
@@ -303,15 +323,28 @@ extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, con
     const int total = g.cin * g.kf * KTP * 32;
     hipLaunchKernelGGL(conv_wt_layout_kernel, dim3(ds2_cdiv(total, 256)), dim3(256), 0, st, weight, g.cin, g.kf, g.kt,
                        0, wt_ws);
-    constexpr int NT = 2;
-    const int ttiles = ds2_cdiv(tout, 32 * NT);
+    // tile width: 64 time steps per wave halves the filter traffic, 32 gives twice the waves; pick the one that
+    // leaves fewer idle SIMD slots in the last round (1024 SIMDs)
+    auto rounds = [&](int nt) {
+        const long waves = (long)B * ds2_cdiv(tout, 32 * nt) * g.fout;
+        return (double)((waves + 1023) / 1024) * nt;
+    };
+    const bool narrow = getenv("DS2_CONV_NT") ? atoi(getenv("DS2_CONV_NT")) == 1 : rounds(1) < rounds(2);
+    const int nt = narrow ? 1 : 2;
+    const int ttiles = ds2_cdiv(tout, 32 * nt);
     const long ntiles = (long)B * ttiles * g.fout;
     dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
-    if (which == 1)
-        hipLaunchKernelGGL((conv_fwd_kernel<1, 41, 2, 2, 10, NT>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
+    if (which == 1 && nt == 2)
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 41, 2, 2, 10, 2>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
+                           g.fout, tout, ttiles, out);
+    else if (which == 1)
+        hipLaunchKernelGGL((conv_fwd_kernel<1, 41, 2, 2, 10, 1>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
+                           g.fout, tout, ttiles, out);
+    else if (nt == 2)
+        hipLaunchKernelGGL((conv_fwd_kernel<32, 21, 2, 1, 0, 2>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
                            g.fout, tout, ttiles, out);
     else
-        hipLaunchKernelGGL((conv_fwd_kernel<32, 21, 2, 1, 0, NT>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
+        hipLaunchKernelGGL((conv_fwd_kernel<32, 21, 2, 1, 0, 1>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
                            g.fout, tout, ttiles, out);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
@@ -325,11 +358,20 @@ extern "C" int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, i
     const int total = 32 * 21 * KTP * 32;
     hipLaunchKernelGGL(conv_wt_layout_kernel, dim3(ds2_cdiv(total, 256)), dim3(256), 0, st, weight, 32, 21, 11, 1,
                        wt_ws);
-    constexpr int NT = 2;
-    const int ttiles = ds2_cdiv(T1, 32 * NT);
+    auto rounds = [&](int nt) {
+        const long waves = (long)B * ds2_cdiv(T1, 32 * nt) * 61;
+        return (double)((waves + 1023) / 1024) * nt;
+    };
+    const bool narrow = getenv("DS2_CONV_NT") ? atoi(getenv("DS2_CONV_NT")) == 1 : rounds(1) < rounds(2);
+    const int nt = narrow ? 1 : 2;
+    const int ttiles = ds2_cdiv(T1, 32 * nt);
     const long ntiles = (long)B * ttiles * 61;
-    hipLaunchKernelGGL((conv2_dgrad_kernel<21, NT>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d_out, wt_ws,
-                       B, 61, T1, 21, T, ttiles, d_in);
+    if (nt == 2)
+        hipLaunchKernelGGL((conv2_dgrad_kernel<21, 2>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d_out,
+                           wt_ws, B, 61, T1, 21, T, ttiles, d_in);
+    else
+        hipLaunchKernelGGL((conv2_dgrad_kernel<21, 1>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d_out,
+                           wt_ws, B, 61, T1, 21, T, ttiles, d_in);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }

@@ -73,7 +73,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
     __shared__ float red[NWP][2][NBT][16][17];
     __shared__ int abort_flag;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // readfirstlane makes everything derived from the wave id provably wave-uniform: uniform branches and SGPR
+    // buffer descriptors instead of per-load waterfall loops (cdna_hip_programming.md T20)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = blockIdx.y, nslice = gridDim.x;
     const int j0 = blockIdx.x * PJU;
     const int m = lane & 15, q = lane >> 4;
@@ -131,9 +134,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
                 const int b = bt * 16 + m;
 #pragma unroll
                 for (int i = 0; i < KBW; ++i) {
-                    const int kb = wave + NWP * i;
-                    const bool ok = (kb < nkb) && (b < B);
-                    dst[i] = ok ? load_sc1_b128(rsrc, (b * H + kb * 16 + q * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int kb = wave + NWP * i;                 // wave-uniform
+                    // rows b >= B lie beyond the descriptor's B*H*4 bytes: the range check returns 0, no branch
+                    dst[i] = (kb < nkb) ? load_sc1_b128(rsrc, (b * H + kb * 16 + q * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
             if (!(dbg & 2)) {
@@ -194,7 +197,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
     __shared__ float red[NWP][NBT][16][17];
     __shared__ int abort_flag;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // readfirstlane makes everything derived from the wave id provably wave-uniform: uniform branches and SGPR
+    // buffer descriptors instead of per-load waterfall loops (cdna_hip_programming.md T20)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = blockIdx.y, nslice = gridDim.x;
     const int j0 = blockIdx.x * PJU;
     const int m = lane & 15, q = lane >> 4;
@@ -258,12 +264,11 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     const int i = i0 + c;
-                    const int kb = wave + NWP * i;
-                    const int k = kb * 16 + q * 4;
-                    const bool ok = (i < KBW) && (kb < nkb) && (b < B);
+                    const int kb = wave + NWP * i;                 // wave-uniform, and so is the source array:
+                    const int k = kb * 16 + q * 4;                 // a 16-wide k block never straddles 2H (H % 8 == 0)
                     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok) {
-                        if (k < 2 * H) v = load_sc1_b128(rs_g, ((b * 2 + dir) * 3 * H + k) * 4);
+                    if (i < KBW && kb < nkb) {                     // rows b >= B: outside the descriptor -> 0
+                        if (kb * 16 < 2 * H) v = load_sc1_b128(rs_g, ((b * 2 + dir) * 3 * H + k) * 4);
                         else v = load_sc1_b128(rs_n, ((b * 2 + dir) * H + (k - 2 * H)) * 4);
                     }
                     dst[c] = v;

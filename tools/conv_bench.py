@@ -1,0 +1,24 @@
+"""Stand-alone timing of the conv kernels at the bench shape (B=10, T_in ~ 830)."""
+import os, sys
+sys.path.insert(0, 'aes-lac-2018_amd'); sys.path.insert(0, '.')
+import torch, numpy as np
+from ds2hip import ops
+B, t_in = int(os.environ.get('BSZ', '10')), int(os.environ.get('TIN', '830'))
+t1, t = ops.conv_out_frames(t_in)
+x = torch.randn(B, 161, t_in, device='cuda'); w1 = torch.randn(32, 1, 41, 11, device='cuda') * 0.05; b1 = torch.zeros(32, device='cuda')
+a1 = torch.randn(B, 32, 61, t1, device='cuda'); w2 = torch.randn(32, 32, 21, 11, device='cuda') * 0.01
+dy2 = torch.randn(B, 32, 21, t, device='cuda'); dy1 = torch.randn(B, 32, 61, t1, device='cuda')
+dw1 = torch.empty_like(w1); dw2 = torch.empty_like(w2); db = torch.empty(32, device='cuda')
+def tm(f, n=8):
+    for _ in range(2): f()
+    torch.cuda.synchronize(); ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+fl2 = 2.0 * B * t * 21 * 32 * 32 * 21 * 11
+print('NT=%s conv1 fwd %.3f ms | conv2 fwd %.3f ms (%.1f TF) dgrad %.3f ms wgrad %.3f ms | conv1 wgrad %.3f ms' % (
+    os.environ.get('DS2_CONV_NT', 'auto'), tm(lambda: ops.conv_fwd(1, x, w1, b1, t_in)), 
+    tm(lambda: ops.conv_fwd(2, a1, w2, b1, t1)), fl2 / tm(lambda: ops.conv_fwd(2, a1, w2, b1, t1)) / 1e9,
+    tm(lambda: ops.conv2_dgrad(dy2, w2, t1)), tm(lambda: ops.conv_wgrad(2, a1, dy2, t1, dw2, db)),
+    tm(lambda: ops.conv_wgrad(1, x, dy1, t_in, dw1, db))))
