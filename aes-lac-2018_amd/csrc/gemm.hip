@@ -20,28 +20,35 @@ constexpr int NI = BK / 8;  // float4 per thread per operand slab
 constexpr int LDT = 132;  // LDS row pitch (floats): 16-B aligned rows, 2-way conflict at worst on writes
 
 // Stage one operand slab [BK][128] into registers.  KCONTIG: the source is X x K (x = m or n).
+// Every load is an UNCONDITIONAL buffer load: an element outside the tile's valid range gets an offset beyond the
+// descriptor and the hardware range check returns 0.  (A guarded or selected load makes hipcc emit a branch and a
+// vmcnt(0) per load -- 320 branches in this kernel before the change.)
+constexpr int OOB = 0x7FFFFFF0;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
+}
+
 template <bool KCONTIG, bool VEC>
-__device__ __forceinline__ void load_slab(const float* __restrict__ src, int ld, int x0, int xmax, int k0,
-                                          int kmax, int tid, f32x4 (&r)[NI]) {
+__device__ __forceinline__ void load_slab(__amdgpu_buffer_rsrc_t rs, int ld, int x0, int xmax, int k0, int kmax,
+                                          int tid, f32x4 (&r)[NI]) {
     if (KCONTIG) {
         const int kq = (tid & (BK / 4 - 1)) * 4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int x = x0 + tid / (BK / 4) + (1024 / BK) * i;
             const int k = k0 + kq;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (x < xmax) {
-                const float* p = src + (size_t)x * ld + k;
-                if (VEC && k + 3 < kmax) {
-                    v = *reinterpret_cast<const f32x4*>(p);
-                } else {
-                    if (k + 0 < kmax) v[0] = p[0];
-                    if (k + 1 < kmax) v[1] = p[1];
-                    if (k + 2 < kmax) v[2] = p[2];
-                    if (k + 3 < kmax) v[3] = p[3];
-                }
+            const int off = (x * ld + k) * 4;
+            if (VEC) {
+                r[i] = bload4(rs, (x < xmax && k + 3 < kmax) ? off : OOB);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[i][c] = bload1(rs, (x < xmax && k + c < kmax) ? off + 4 * c : OOB);
             }
-            r[i] = v;
         }
     } else {
         const int xq = (tid & 31) * 4;
@@ -49,19 +56,18 @@ __device__ __forceinline__ void load_slab(const float* __restrict__ src, int ld,
         for (int i = 0; i < NI; ++i) {
             const int k = k0 + (tid >> 5) + 8 * i;
             const int x = x0 + xq;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < kmax) {
-                const float* p = src + (size_t)k * ld + x;
-                if (VEC && x + 3 < xmax) {
-                    v = *reinterpret_cast<const f32x4*>(p);
+            const int off = (k * ld + x) * 4;
+            if (VEC) {
+                if (x + 3 < xmax || x >= xmax) {          // whole chunk in or out (the common case, no per-element work)
+                    r[i] = bload4(rs, (k < kmax && x < xmax) ? off : OOB);
                 } else {
-                    if (x + 0 < xmax) v[0] = p[0];
-                    if (x + 1 < xmax) v[1] = p[1];
-                    if (x + 2 < xmax) v[2] = p[2];
-                    if (x + 3 < xmax) v[3] = p[3];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[i][c] = bload1(rs, (k < kmax && x + c < xmax) ? off + 4 * c : OOB);
                 }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[i][c] = bload1(rs, (k < kmax && x + c < xmax) ? off + 4 * c : OOB);
             }
-            r[i] = v;
         }
     }
 }
@@ -90,7 +96,8 @@ template <bool A_KCONTIG, bool B_KCONTIG, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
                                                           int lda, const float* __restrict__ B, int ldb,
                                                           float* __restrict__ C, int ldc, float beta,
-                                                          int tiles_n, int k_per_split, int use_atomic) {
+                                                          int tiles_n, int k_per_split, int use_atomic,
+                                                          unsigned int a_bytes, unsigned int b_bytes) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDT];  // [buf][A|B]
 
     const int tid = threadIdx.x;
@@ -118,11 +125,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, b_bytes, 0x00020000);
     f32x4 ra[NI], rb[NI];
     const int nslab = (kend - kbeg + BK - 1) / BK;
     if (nslab > 0) {
-        load_slab<A_KCONTIG, VEC>(A, lda, m0, M, kbeg, kend, tid, ra);
-        load_slab<B_KCONTIG, VEC>(B, ldb, n0, N, kbeg, kend, tid, rb);
+        load_slab<A_KCONTIG, VEC>(rsa, lda, m0, M, kbeg, kend, tid, ra);
+        load_slab<B_KCONTIG, VEC>(rsb, ldb, n0, N, kbeg, kend, tid, rb);
         store_slab<A_KCONTIG>(lds[0][0], tid, ra);
         store_slab<B_KCONTIG>(lds[0][1], tid, rb);
     }
@@ -132,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, c
     for (int s = 0; s < nslab; ++s) {
         const int cur = s & 1;
         if (s + 1 < nslab) {
-            load_slab<A_KCONTIG, VEC>(A, lda, m0, M, kbeg + (s + 1) * BK, kend, tid, ra);
-            load_slab<B_KCONTIG, VEC>(B, ldb, n0, N, kbeg + (s + 1) * BK, kend, tid, rb);
+            load_slab<A_KCONTIG, VEC>(rsa, lda, m0, M, kbeg + (s + 1) * BK, kend, tid, ra);
+            load_slab<B_KCONTIG, VEC>(rsb, ldb, n0, N, kbeg + (s + 1) * BK, kend, tid, rb);
         }
         const float* as = lds[cur][0] + wm * 64 + lr;
         const float* bs = lds[cur][1] + wn * 64 + lr;
@@ -196,17 +205,22 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
     int kper = ds2_cdiv(ds2_cdiv(K, split_k), BK) * BK;
     if (kper < BK) kper = BK;
     const int nsplit = ds2_cdiv(K, kper);
-    const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0);
+    const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
+                     ((!AK && !BKc) || K % 4 == 0);
+    // bytes each descriptor must cover (rows x ld, last row only as wide as it is used)
+    const unsigned long long abytes = 4ull * (AK ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
+    const unsigned long long bbytes = 4ull * (BKc ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
+    if (abytes >= 0x7FFFFFF0ull || bbytes >= 0x7FFFFFF0ull) return -1;
     dim3 grid(tm * tn, nsplit), block(256);
     const int atomic = nsplit > 1 ? 1 : 0;
     if (atomic && beta == 0.f)  // partial products are accumulated with atomics: start from zero
         (void)hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
     if (vec)
         hipLaunchKernelGGL((gemm_f32_kernel<AK, BKc, true>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc,
-                           beta, tn, kper, atomic);
+                           beta, tn, kper, atomic, (unsigned int)abytes, (unsigned int)bbytes);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<AK, BKc, false>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc,
-                           beta, tn, kper, atomic);
+                           beta, tn, kper, atomic, (unsigned int)abytes, (unsigned int)bbytes);
     return 0;
 }
 
@@ -220,10 +234,15 @@ extern "C" int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
     DS2_CHECK_ARG(split_k >= 0);
     DS2_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N);
     hipStream_t st = (hipStream_t)stream;
-    if (!trans_a && !trans_b) launch<true, false>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
-    else if (!trans_a && trans_b) launch<true, true>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
-    else if (trans_a && !trans_b) launch<false, false>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
-    else launch<false, true>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    int rc;
+    if (!trans_a && !trans_b) rc = launch<true, false>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    else if (!trans_a && trans_b) rc = launch<true, true>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    else if (trans_a && !trans_b) rc = launch<false, false>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    else rc = launch<false, true>(M, N, K, A, lda, B, ldb, C, ldc, beta, split_k, st);
+    if (rc != 0) {
+        ds2_set_error("ds2_gemm_f32: operand larger than 2 GB is not supported");
+        return DS2_ERR_UNSUPPORTED;
+    }
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }

@@ -7,7 +7,8 @@ rows = int(os.environ.get('ROWS', '4240'))
 shapes = [('gi   NT', 0, 1, rows, 4800, 800, 1), ('gi0  NT', 0, 1, rows, 4800, 672, 1),
           ('dX   NN', 0, 0, rows, 800, 4800, 0), ('dWih TN', 1, 0, 4800, 800, rows, 0),
           ('dWhh TN', 1, 0, 1600, 800, rows, 0), ('dWhn TN', 1, 0, 800, 800, rows, 0),
-          ('sq   NT', 0, 1, 4096, 4096, 4096, 1)]
+          ('sq   NT', 0, 1, 4096, 4096, 4096, 1), ('k800 NT', 0, 1, 4096, 4096, 800, 1), ('k800 NT', 0, 1, 4096, 4736, 800, 1),
+          ('k800 NT', 0, 1, 8192, 4096, 800, 1), ('k800 NT', 0, 1, 2048, 4096, 800, 1)]
 for name, ta, tb, m, n, k, sk in shapes:
     a = torch.randn((k, m) if ta else (m, k), device='cuda'); b = torch.randn((n, k) if tb else (k, n), device='cuda')
     c = torch.empty(m, n, device='cuda')
