@@ -57,6 +57,21 @@ def test_train_then_test_cli(tmp_path):
     assert 'Test Summary' in out.stdout and 'Average CER' in out.stdout
 
 
+def test_train_cli_distributed_launch(tmp_path):
+    """train.py without --local under torch.distributed.run (one rank): RCCL group, DistributedBucketingSampler,
+    rank-0 checkpointing."""
+    _corpus(tmp_path)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                          '--master-addr', '127.0.0.1', '--master-port', '29641', os.path.join(ROOT, 'train.py'),
+                          str(tmp_path / 'tiny.json'), '--data-dir', str(tmp_path), '--train-manifest',
+                          str(tmp_path / 'train.csv'), '--val-manifest', str(tmp_path / 'val.csv'), '--checkpoint',
+                          '--num-workers', '0', '--save-folder', str(tmp_path / 'results_ddp')],
+                         capture_output=True, text=True, env=dict(os.environ), timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert 'Validation Summary Epoch: [2]' in (out.stderr + out.stdout)
+    assert (tmp_path / 'results_ddp' / 'tiny' / 'model_ckpt_2.pth').exists()
+
+
 def test_trainer_distributed_path_single_rank():
     """With a process group initialised the trainer broadcasts, all-reduces per-layer slices on a side stream and
     folds 1/world into the update: with world = 1 the result must equal the non-distributed step (up to atomic-add ordering)."""
