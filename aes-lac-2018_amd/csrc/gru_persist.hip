@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
 
     for (int s = 0; s < T; ++s) {
         const int t = dir == 0 ? s : T - 1 - s;
-        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
+        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
         size_t gbase = 0;
         if (gate_ok) {                                  // independent of h: issue before the wait
             gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
@@ -177,14 +177,20 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             const float h = (1.f - z) * n + z * hp;
             hp = h;
             store_sc1(&hout[(((size_t)dir * T + t) * B + gb) * H + gj], h);   // handed to every other workgroup
-            G[gbase] = r;
-            G[gbase + H] = z;
-            G[gbase + 2 * H] = n;
-            ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = gh_n;
+            sv_r = r;
+            sv_z = z;
+            sv_n = n;
+            sv_g = gh_n;
         }
-        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores
+        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gate_ok) {   // saved activations are only read by later launches: keep them off the hand-off's critical path
+            G[gbase] = sv_r;
+            G[gbase + H] = sv_z;
+            G[gbase + 2 * H] = sv_n;
+            ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g;
+        }
     }
 }
 
