@@ -41,6 +41,12 @@ __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int 
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */);
     return __builtin_bit_cast(f32x4, v);
 }
+__device__ __forceinline__ f32x4 load_plain_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+// hand-off payload load: dbg bit 5 (32) = timing experiment with plain (L2-allocating) loads
+#define LOAD_HANDOFF(rs, off) ((dbg & 32) ? load_plain_b128(rs, off) : load_sc1_b128(rs, off))
 __device__ __forceinline__ void store_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
                 for (int i = 0; i < KBW; ++i) {
                     const int kb = wave + NWP * i;                 // wave-uniform
                     // rows b >= B lie beyond the descriptor's B*H*4 bytes: the range check returns 0, no branch
-                    dst[i] = (kb < nkb) ? load_sc1_b128(rsrc, (b * H + kb * 16 + q * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    dst[i] = (kb < nkb) ? LOAD_HANDOFF(rsrc, (b * H + kb * 16 + q * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
             if (!(dbg & 2)) {
@@ -274,8 +280,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
                     const int k = kb * 16 + q * 4;                 // a 16-wide k block never straddles 2H (H % 8 == 0)
                     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (i < KBW && kb < nkb) {                     // rows b >= B: outside the descriptor -> 0
-                        if (kb * 16 < 2 * H) v = load_sc1_b128(rs_g, ((b * 2 + dir) * 3 * H + k) * 4);
-                        else v = load_sc1_b128(rs_n, ((b * 2 + dir) * H + (k - 2 * H)) * 4);
+                        if (kb * 16 < 2 * H) v = LOAD_HANDOFF(rs_g, ((b * 2 + dir) * 3 * H + k) * 4);
+                        else v = LOAD_HANDOFF(rs_n, ((b * 2 + dir) * H + (k - 2 * H)) * 4);
                     }
                     dst[c] = v;
                 }

@@ -225,6 +225,27 @@ def main():
         return
 
     value = frames / dt
+
+    # secondary metric: inference = frontend + eval forward + greedy decode, same bins, rank 0 only
+    from codes.decoder import GreedyDecoder
+    decoder = GreedyDecoder(['_', ' ', "'"] + [chr(65 + i) for i in range(26)])
+    model.eval()
+    inf_frames, n_inf = 0, min(12, len(resident))
+    with torch.no_grad():
+        for i in range(2):                                               # warm-up
+            inputs, pct = front(resident[i][0], resident[i][1])
+            model(inputs)
+        torch.cuda.synchronize()
+        ti = time.time()
+        for i in range(n_inf):
+            inputs, pct = front(resident[i][0], resident[i][1])
+            probs = model(inputs)
+            sizes = (pct * probs.shape[1]).int()
+            decoder.decode(probs, sizes)
+            inf_frames += frames_of(mine[i])
+        torch.cuda.synchronize()
+        inf_dt = time.time() - ti
+    model.train()
     step_tflops = osteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12 / world    # per GPU, padded steps included
     t_mean = int(round(np.mean([out_steps_of(b) / len(b[0]) for b in mine])))
     roof = gru_pass_roofline(model, bsz, t_mean)
@@ -245,7 +266,8 @@ def main():
                                '16 kHz clips uniform 1-15 s in length-sorted bins, full train step incl. GPU STFT '
                                'frontend, CTC, clip+SGD' % bsz,
                    'batch_per_gpu': bsz, 'global_batch': bsz * world, 'parallelism': 'dp%d' % world,
-                   'last_loss': round(float(loss), 4)},
+                   'last_loss': round(float(loss), 4),
+                   'inference_frames_per_s_rank0': round(inf_frames / inf_dt, 1)},
         'roofline': {'bound': 'mfma',
                      'kernel': 'gru_bwd_persistent_kernel (one launch = all T=%d steps of a BiGRU layer, both '
                                'directions, B=%d)' % (t_mean, bsz),
