@@ -154,8 +154,10 @@ class Trainer(object):
         comm = self._comm_stream
         gflat = self.model.flat_grad()
 
-        def ready(lo, hi):
+        def ready(lo, hi, also_wait=None):
             comm.wait_stream(torch.cuda.current_stream())
+            if also_wait is not None:              # weight-gradient GEMMs of this slice run on a side stream
+                comm.wait_stream(also_wait)
             with torch.cuda.stream(comm):
                 dist.all_reduce(gflat[lo:hi])
         return ready

@@ -19,6 +19,7 @@ fused kernel applies clip + Nesterov SGD to everything.
 Out of scope: unidirectional + Lookahead, LSTM/RNN cells, multi-task heads.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -154,6 +155,8 @@ class DeepSpeech(nn.Module):
         self._flat_p = None
         self._flat_g = None
         self._plist, self._offsets = [], []
+        self.overlap_wgrad = os.environ.get('DS2_OVERLAP_WGRAD', '1') != '0'
+        self._side = None
 
     # ------------------------------------------------------------------ flat parameter storage
     def _flat_order(self):
@@ -327,6 +330,12 @@ class DeepSpeech(nn.Module):
             grad_ready(*self._span(head[0].weight, head[1].weight))
         nl = len(sv['layers'])
         f4 = 4
+        # The weight-gradient GEMMs of a layer (dW_ih, dW_hh) are not on the chain that feeds the next (lower) layer:
+        # chain = d(gi) -> dX GEMM -> BatchNorm backward -> recurrence of the layer below.  They go to a LOW-priority
+        # side stream and fill the ~56 CUs the persistent recurrence kernel (200 workgroups) leaves idle.
+        main = torch.cuda.current_stream()
+        side = self._side_stream(gflat.device) if self.overlap_wgrad else None
+        keepalive = []
         for li in range(nl - 1, -1, -1):
             rec = sv['layers'][li]
             layer = self.rnns[li]
@@ -339,25 +348,28 @@ class DeepSpeech(nn.Module):
             ops.transpose2d(w_hh[1], 3 * hid, hid, out=w_hh_t[1])
             gates, ghn, hout = rec['gates'], rec['ghn'], rec['hout']
             ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid)           # gates -> d(gi), ghn -> d(gh_n)
-            # dW_hh[d] = dGH[d]^T h_prev[d]; forward dir pairs step t with h[t-1], reverse with h[t+1]
-            g_hh = (gv(r.weight_hh_l0), gv(r.weight_hh_l0_reverse))
-            if t > 1:
-                k = (t - 1) * bsz
-                step_g, step_n = bsz * 6 * hid * f4, bsz * 2 * hid * f4
-                for d in (0, 1):
-                    a_g = gates.data_ptr() + d * 3 * hid * f4 + (step_g if d == 0 else 0)
-                    a_n = ghn.data_ptr() + d * hid * f4 + (step_n if d == 0 else 0)
-                    hp = hout[d].data_ptr() + (0 if d == 0 else bsz * hid * f4)
-                    ops.gemm_raw(1, 0, 2 * hid, hid, k, a_g, 6 * hid, hp, hid, g_hh[d].data_ptr(), hid, split_k=0)
-                    ops.gemm_raw(1, 0, hid, hid, k, a_n, 2 * hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4, hid,
-                                 split_k=0)
-            else:
-                g_hh[0].zero_()
-                g_hh[1].zero_()
             dgi = gates.view(rows, 6 * hid)
+            dxin = ops.gemm(dgi, w_ih, split_k=0)                                   # (rows, n_in): on the chain
+            g_hh = (gv(r.weight_hh_l0), gv(r.weight_hh_l0_reverse))
             g_ih = self._pair_view(gflat, r.weight_ih_l0, r.weight_ih_l0_reverse)
-            ops.gemm(dgi, rec['xin'].view(rows, n_in), trans_a=True, out=g_ih, split_k=0)      # dW_ih (both dirs)
-            dxin = ops.gemm(dgi, w_ih, split_k=0)                                              # (rows, n_in)
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                # dW_hh[d] = dGH[d]^T h_prev[d]; forward dir pairs step t with h[t-1], reverse with h[t+1]
+                if t > 1:
+                    k = (t - 1) * bsz
+                    step_g, step_n = bsz * 6 * hid * f4, bsz * 2 * hid * f4
+                    for d in (0, 1):
+                        a_g = gates.data_ptr() + d * 3 * hid * f4 + (step_g if d == 0 else 0)
+                        a_n = ghn.data_ptr() + d * hid * f4 + (step_n if d == 0 else 0)
+                        hp = hout[d].data_ptr() + (0 if d == 0 else bsz * hid * f4)
+                        ops.gemm_raw(1, 0, 2 * hid, hid, k, a_g, 6 * hid, hp, hid, g_hh[d].data_ptr(), hid, split_k=0)
+                        ops.gemm_raw(1, 0, hid, hid, k, a_n, 2 * hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4,
+                                     hid, split_k=0)
+                else:
+                    g_hh[0].zero_()
+                    g_hh[1].zero_()
+                ops.gemm(dgi, rec['xin'].view(rows, n_in), trans_a=True, out=g_ih, split_k=0)  # dW_ih (both dirs)
             if layer.batch_norm is not None:
                 bn = layer.batch_norm.module
                 below = sv['layers'][li - 1]['hout']
@@ -367,8 +379,13 @@ class DeepSpeech(nn.Module):
                 dy = dxin
             if grad_ready is not None:
                 first = layer.batch_norm.module.weight if layer.batch_norm is not None else r.weight_ih_l0
-                grad_ready(*self._span(first, r.weight_hh_l0_reverse))
+                grad_ready(*self._span(first, r.weight_hh_l0_reverse), also_wait=side)
+            if side is not None:
+                keepalive.append(dict(rec))        # the side stream still reads these; freed after the join below
             rec.clear()
+        if side is not None:
+            main.wait_stream(side)                  # every later consumer of the gradients sits behind this join
+        keepalive.clear()
         c = self.conv
         if sv.get('conv_frozen', False):             # frozen conv block: nothing upstream needs a gradient
             lo, hi = self._span(c[0].weight, c[4].bias)
@@ -384,6 +401,16 @@ class DeepSpeech(nn.Module):
         ops.conv_wgrad(1, sv['xt'], d_y1, t_in, gv(c[0].weight), gv(c[0].bias))
         if grad_ready is not None:
             grad_ready(*self._span(c[0].weight, c[4].bias))
+
+    def _side_stream(self, dev):
+        st = getattr(self, '_side', None)
+        if st is None or st.device != dev:
+            try:
+                lo, _hi = torch.cuda.Stream.priority_range()      # (lowest, highest priority)
+            except Exception:                                     # noqa: BLE001 - older torch: no query, default priority
+                lo = 0
+            st = self._side = torch.cuda.Stream(device=dev, priority=lo)
+        return st
 
     def _pair_view(self, gflat, p_fwd, p_rev):
         n = p_fwd.numel()
