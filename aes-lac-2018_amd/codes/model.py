@@ -395,10 +395,15 @@ class DeepSpeech(nn.Module):
             return
         d_a2 = ops.transpose2d(dy, t, bsz * self._rnn_input_size).view(bsz, 32, 21, t)   # (T,B,672) -> (B,32,21,T)
         d_y2 = ops.bn2d_htanh_bwd(sv['y2'], d_a2, sv['mi2'], c[4].weight, c[4].bias, gv(c[4].weight), gv(c[4].bias))
-        ops.conv_wgrad(2, sv['a1'], d_y2, t1, gv(c[3].weight), gv(c[3].bias))
+        if side is not None:                         # conv2's filter gradient is off the dgrad -> BN1 -> conv1 chain
+            side.wait_stream(main)
+        with torch.cuda.stream(side if side is not None else main):
+            ops.conv_wgrad(2, sv['a1'], d_y2, t1, gv(c[3].weight), gv(c[3].bias))
         d_a1 = ops.conv2_dgrad(d_y2, c[3].weight, t1)
         d_y1 = ops.bn2d_htanh_bwd(sv['y1'], d_a1, sv['mi1'], c[1].weight, c[1].bias, gv(c[1].weight), gv(c[1].bias))
         ops.conv_wgrad(1, sv['xt'], d_y1, t_in, gv(c[0].weight), gv(c[0].bias))
+        if side is not None:
+            main.wait_stream(side)
         if grad_ready is not None:
             grad_ready(*self._span(c[0].weight, c[4].bias))
 
