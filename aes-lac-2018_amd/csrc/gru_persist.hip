@@ -75,7 +75,8 @@ template <int NBT, int KBW>
 __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                       float* __restrict__ hout,
                                                                       const float* __restrict__ w_hh,
-                                                                      SyncWs* __restrict__ sync, int T, int B, int H, int dbg) {
+                                                                      SyncWs* __restrict__ sync, float* __restrict__ ring,
+                                                                      int T, int B, int H, int dbg) {
     __shared__ float red[NWP][2][NBT][16][17];
     __shared__ int abort_flag;
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
 
     for (int s = 0; s < T; ++s) {
         const int t = dir == 0 ? s : T - 1 - s;
-        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
+        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f, sv_h = 0.f;
         size_t gbase = 0;
         if (gate_ok) {                                  // independent of h: issue before the wait
             gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
@@ -129,20 +130,22 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
                 abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
-            const int tprev = dir == 0 ? t - 1 : t + 1;
-            const float* hprev = hout + ((size_t)dir * T + tprev) * B * H;
-            const __amdgpu_buffer_rsrc_t rsrc =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hprev), 0, B * H * 4, 0x00020000);
+            // h_{t-1} comes from the exchange ring, laid out [batch tile][k block][16 batch rows][16 k] so that one
+            // wave-load (64 lanes x 16 B) is ONE contiguous kilobyte = eight whole 128-B lines (the (b, k) layout of
+            // hout gives 10-16 scattered 64-B pieces per load and ran the CU's inbound path at ~27 GB/s)
+            const int slot_floats = NBT * nkb * 256;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
             // batch tiles are software-pipelined: the h fragments of tile bt+1 are in flight while the MFMAs of
             // tile bt issue (fully unrolled so the two fragment buffers stay in registers)
             f32x4 bf[2][KBW];
             auto fetch = [&](int bt, f32x4 (&dst)[KBW]) {
-                const int b = bt * 16 + m;
 #pragma unroll
                 for (int i = 0; i < KBW; ++i) {
                     const int kb = wave + NWP * i;                 // wave-uniform
-                    // rows b >= B lie beyond the descriptor's B*H*4 bytes: the range check returns 0, no branch
-                    dst[i] = (kb < nkb) ? LOAD_HANDOFF(rsrc, (b * H + kb * 16 + q * 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    // rows of padding batch entries are never written and stay zero (the ring is zeroed per launch)
+                    dst[i] = (kb < nkb) ? LOAD_HANDOFF(rsrc, (((bt * nkb + kb) * 16 + m) * 16 + q * 4) * 4)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
             if (!(dbg & 2)) {
@@ -182,7 +185,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             const float n = tanhf(gi_n + r * gh_n);
             const float h = (1.f - z) * n + z * hp;
             hp = h;
-            store_sc1(&hout[(((size_t)dir * T + t) * B + gb) * H + gj], h);   // handed to every other workgroup
+            // handed to every other workgroup through the ring; hout keeps the plain copy for later launches
+            store_sc1(&ring[(((size_t)dir * 2 + (s & 1)) * NBT * nkb + (size_t)gbt * nkb + (gj >> 4)) * 256 + nn * 16 +
+                            (gj & 15)], h);
+            sv_h = h;
             sv_r = r;
             sv_z = z;
             sv_n = n;
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // saved activations are only read by later launches: keep them off the hand-off's critical path
+            hout[(((size_t)dir * T + t) * B + gb) * H + gj] = sv_h;
             G[gbase] = sv_r;
             G[gbase + H] = sv_z;
             G[gbase + 2 * H] = sv_n;
@@ -205,7 +212,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
                                                                       const float* __restrict__ hout,
                                                                       const float* __restrict__ d_out,
                                                                       const float* __restrict__ w_hh_t,
-                                                                      SyncWs* __restrict__ sync, int T, int B, int H, int dbg) {
+                                                                      SyncWs* __restrict__ sync, float* __restrict__ ring,
+                                                                      int T, int B, int H, int dbg) {
     __shared__ float red[NWP][NBT][16][17];
     __shared__ int abort_flag;
 
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
         const int tnext = dir == 0 ? t + 1 : t - 1;
         const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
         // saved activations of step t (written by the forward pass, an earlier launch): plain loads
-        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
+        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
         size_t row = 0, gbase = 0;
         if (gate_ok) {
             row = ((size_t)t * B + gb) * 2 + dir;
@@ -260,11 +268,11 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
                 abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
-            // dGH of step tnext: [dr_pre | dz_pre] from G, d(gh_n) from ghn -- all stored sc1 by their owners
-            const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
-                G + (size_t)tnext * B * 6 * H, 0, B * 6 * H * 4, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
-                ghn + (size_t)tnext * B * 2 * H, 0, B * 2 * H * 4, 0x00020000);
+            // dGH of step tnext = [dr_pre | dz_pre | d(gh_n)] comes from the exchange ring, laid out
+            // [batch tile][k block][16 batch rows][16 k]: one wave-load = one contiguous kilobyte
+            const int slot_floats = NBT * nkb * 256;
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
             // stages = (batch tile, k chunk); the fragments of stage st+1 are fetched while stage st's MFMAs issue
             constexpr int CH = (NBT > 1 && KBW > 10) ? 7 : KBW;
             constexpr int NCH = (KBW + CH - 1) / CH;
@@ -272,18 +280,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
             f32x4 bf[2][CH];
             auto fetch = [&](int st, f32x4 (&dst)[CH]) {
                 const int bt = st / NCH, i0 = (st % NCH) * CH;
-                const int b = bt * 16 + m;
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
                     const int i = i0 + c;
-                    const int kb = wave + NWP * i;                 // wave-uniform, and so is the source array:
-                    const int k = kb * 16 + q * 4;                 // a 16-wide k block never straddles 2H (H % 8 == 0)
-                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (i < KBW && kb < nkb) {                     // rows b >= B: outside the descriptor -> 0
-                        if (kb * 16 < 2 * H) v = LOAD_HANDOFF(rs_g, ((b * 2 + dir) * 3 * H + k) * 4);
-                        else v = LOAD_HANDOFF(rs_n, ((b * 2 + dir) * H + (k - 2 * H)) * 4);
-                    }
-                    dst[c] = v;
+                    const int kb = wave + NWP * i;                 // wave-uniform
+                    dst[c] = (i < KBW && kb < nkb) ? LOAD_HANDOFF(rs_x, (((bt * nkb + kb) * 16 + m) * 16 + q * 4) * 4)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
             if (!(dbg & 2)) {
@@ -320,14 +322,27 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
             const float dz_pre = dh * (hpv - n) * z * (1.f - z);
             const float dr_pre = dn_pre * gn * r * (1.f - r);
             dhz = dh * z;
-            store_sc1(&G[gbase], dr_pre);
-            store_sc1(&G[gbase + H], dz_pre);
-            store_sc1(&G[gbase + 2 * H], dn_pre);
-            store_sc1(&ghn[row * H + gj], dn_pre * r);
+            {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
+                float* slot = ring + (((size_t)dir * 2 + (s & 1)) * NBT + gbt) * (size_t)nkb * 256 + nn * 16;
+                const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
+                store_sc1(&slot[(size_t)(k0 >> 4) * 256 + (k0 & 15)], dr_pre);
+                store_sc1(&slot[(size_t)(k1 >> 4) * 256 + (k1 & 15)], dz_pre);
+                store_sc1(&slot[(size_t)(k2 >> 4) * 256 + (k2 & 15)], dn_pre * r);
+            }
+            sv_r = dr_pre;
+            sv_z = dz_pre;
+            sv_n = dn_pre;
+            sv_g = dn_pre * r;
         }
         if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
+            G[gbase] = sv_r;
+            G[gbase + H] = sv_z;
+            G[gbase + 2 * H] = sv_n;
+            ghn[row * H + gj] = sv_g;
+        }
     }
 }
 
@@ -338,15 +353,15 @@ inline int pick_kbw(int need, const int* opts, int nopts) {
 }
 
 template <int NBT>
-bool launch_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, int T, int B, int H,
-                           int dbg, hipStream_t st) {
+bool launch_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
+                           int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 4, 7};
     const int kbw = pick_kbw(ds2_cdiv(H / 16, NWP), opts, 4);
     dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
 #define DS2_FWD_CASE(K)                                                                                              \
     case K:                                                                                                          \
-        hipLaunchKernelGGL((gru_fwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, T, B, H, \
-                           dbg);                                                                                   \
+        hipLaunchKernelGGL((gru_fwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, ring, T, B,  \
+                           H, dbg);                                                                                   \
         return true;
     switch (kbw) {
         DS2_FWD_CASE(1)
@@ -360,14 +375,14 @@ bool launch_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh,
 
 template <int NBT>
 bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
-                           SyncWs* sync, int T, int B, int H, int dbg, hipStream_t st) {
+                           SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 4, 8, 19};
     const int kbw = pick_kbw(ds2_cdiv(3 * H / 16, NWP), opts, 5);
     dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
 #define DS2_BWD_CASE(K)                                                                                          \
     case K:                                                                                                      \
         hipLaunchKernelGGL((gru_bwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, \
-                           sync, T, B, H, dbg);                                                                  \
+                           sync, ring, T, B, H, dbg);                                                            \
         return true;
     switch (kbw) {
         DS2_BWD_CASE(1)
@@ -399,11 +414,10 @@ inline int dbg_flags() {
 // A data-tagged-granule hand-off (Guideline 16 R2: every consumer wave polls the 8-byte {value, epoch} granules it
 // needs) was built and measured in round 1: correct, but 1.5x (forward) to 2.1x (backward) SLOWER per step than the
 // counter form -- 1600 waves polling payload lines swamp the fabric ("polling-cost" row of the price list).
-extern "C" size_t ds2_gru_sync_ws_bytes(int B, int H) {
-    (void)B;
-    (void)H;
-    return header_bytes();
-}
+// exchange ring: [dir 2][slot 2][batch tiles][k blocks of 16][16][16] floats, sized for the backward pass (K = 3H)
+inline size_t ring_floats(int B, int H) { return (size_t)2 * 2 * ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256; }
+
+extern "C" size_t ds2_gru_sync_ws_bytes(int B, int H) { return header_bytes() + ring_floats(B, H) * sizeof(float); }
 
 extern "C" size_t ds2_gru_sync_error_offset(void) { return offsetof(SyncWs, error); }
 
@@ -419,12 +433,14 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     }
     hipStream_t st = (hipStream_t)stream;
     SyncWs* sync = (SyncWs*)sync_ws;
-    DS2_HIP(hipMemsetAsync(sync, 0, header_bytes(), st));
+    float* ring = (float*)((char*)sync_ws + header_bytes());
+    // counters AND ring are zeroed: padding batch rows of the ring must read as 0
+    DS2_HIP(hipMemsetAsync(sync_ws, 0, header_bytes() + ring_floats(B, H) * sizeof(float), st));
     const int dbg = dbg_flags();
     bool ok;
-    if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, T, B, H, dbg, st);
-    else if (B <= 32) ok = launch_fwd_persistent<2>(G, ghn, hout, w_hh, sync, T, B, H, dbg, st);
-    else ok = launch_fwd_persistent<4>(G, ghn, hout, w_hh, sync, T, B, H, dbg, st);
+    if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    else if (B <= 32) ok = launch_fwd_persistent<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    else ok = launch_fwd_persistent<4>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     DS2_CHECK_ARG(ok);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
@@ -440,12 +456,13 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     }
     hipStream_t st = (hipStream_t)stream;
     SyncWs* sync = (SyncWs*)sync_ws;
-    DS2_HIP(hipMemsetAsync(sync, 0, header_bytes(), st));
+    float* ring = (float*)((char*)sync_ws + header_bytes());
+    DS2_HIP(hipMemsetAsync(sync_ws, 0, header_bytes() + ring_floats(B, H) * sizeof(float), st));
     const int dbg = dbg_flags();
     bool ok;
-    if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, T, B, H, dbg, st);
-    else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, T, B, H, dbg, st);
-    else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, T, B, H, dbg, st);
+    if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     DS2_CHECK_ARG(ok);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
