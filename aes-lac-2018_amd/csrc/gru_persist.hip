@@ -2,6 +2,8 @@
 #include <stddef.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ds2_common.h"
 
 // ==========================================================================================================
@@ -130,9 +132,11 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
                 abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
-            // h_{t-1} comes from the exchange ring, laid out [batch tile][k block][16 batch rows][16 k] so that one
-            // wave-load (64 lanes x 16 B) is ONE contiguous kilobyte = eight whole 128-B lines (the (b, k) layout of
-            // hout gives 10-16 scattered 64-B pieces per load and ran the CU's inbound path at ~27 GB/s)
+            // h_{t-1} comes from the exchange ring, laid out [batch tile][k block][k quad 4][16 batch rows][4 k]: the
+            // MFMA B fragment of lane l is bytes 16 l .. 16 l + 15 of ONE contiguous kilobyte, so a wave-load is eight
+            // whole 128-B lines read in lane order (the (b, k) layout of hout gives 10-16 scattered 64-B pieces per
+            // load and ran the CU's inbound path at ~27 GB/s; a [16 batch][16 k] block is contiguous per wave but
+            // each 16-lane quarter still gathers four 64-B pieces and measured ~1 us/step slower)
             const int slot_floats = NBT * nkb * 256;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
                 for (int i = 0; i < KBW; ++i) {
                     const int kb = wave + NWP * i;                 // wave-uniform
                     // rows of padding batch entries are never written and stay zero (the ring is zeroed per launch)
-                    dst[i] = (kb < nkb) ? LOAD_HANDOFF(rsrc, (((bt * nkb + kb) * 16 + m) * 16 + q * 4) * 4)
+                    dst[i] = (kb < nkb) ? LOAD_HANDOFF(rsrc, ((bt * nkb + kb) * 256 + lane * 4) * 4)
                                         : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             const float h = (1.f - z) * n + z * hp;
             hp = h;
             // handed to every other workgroup through the ring; hout keeps the plain copy for later launches
-            store_sc1(&ring[(((size_t)dir * 2 + (s & 1)) * NBT * nkb + (size_t)gbt * nkb + (gj >> 4)) * 256 + nn * 16 +
-                            (gj & 15)], h);
+            store_sc1(&ring[(((size_t)dir * 2 + (s & 1)) * NBT * nkb + (size_t)gbt * nkb + (gj >> 4)) * 256 +
+                            ((gj & 15) >> 2) * 64 + nn * 4 + (gj & 3)], h);
             sv_h = h;
             sv_r = r;
             sv_z = z;
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
                 for (int c = 0; c < CH; ++c) {
                     const int i = i0 + c;
                     const int kb = wave + NWP * i;                 // wave-uniform
-                    dst[c] = (i < KBW && kb < nkb) ? LOAD_HANDOFF(rs_x, (((bt * nkb + kb) * 16 + m) * 16 + q * 4) * 4)
+                    dst[c] = (i < KBW && kb < nkb) ? LOAD_HANDOFF(rs_x, ((bt * nkb + kb) * 256 + lane * 4) * 4)
                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
@@ -323,11 +327,185 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
             const float dr_pre = dn_pre * gn * r * (1.f - r);
             dhz = dh * z;
             {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
-                float* slot = ring + (((size_t)dir * 2 + (s & 1)) * NBT + gbt) * (size_t)nkb * 256 + nn * 16;
+                float* slot = ring + (((size_t)dir * 2 + (s & 1)) * NBT + gbt) * (size_t)nkb * 256 + nn * 4;
                 const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
-                store_sc1(&slot[(size_t)(k0 >> 4) * 256 + (k0 & 15)], dr_pre);
-                store_sc1(&slot[(size_t)(k1 >> 4) * 256 + (k1 & 15)], dz_pre);
-                store_sc1(&slot[(size_t)(k2 >> 4) * 256 + (k2 & 15)], dn_pre * r);
+                store_sc1(&slot[(size_t)(k0 >> 4) * 256 + ((k0 & 15) >> 2) * 64 + (k0 & 3)], dr_pre);
+                store_sc1(&slot[(size_t)(k1 >> 4) * 256 + ((k1 & 15) >> 2) * 64 + (k1 & 3)], dz_pre);
+                store_sc1(&slot[(size_t)(k2 >> 4) * 256 + ((k2 & 15) >> 2) * 64 + (k2 & 3)], dn_pre * r);
+            }
+            sv_r = dr_pre;
+            sv_z = dz_pre;
+            sv_n = dn_pre;
+            sv_g = dn_pre * r;
+        }
+        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
+            G[gbase] = sv_r;
+            G[gbase + H] = sv_z;
+            G[gbase + 2 * H] = sv_n;
+            ghn[row * H + gj] = sv_g;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Backward recurrence on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per instruction).
+//
+// A workgroup owns 8 hidden units = 8 rows of w_hh_t: half a 16x16x4 tile, so half of every MFMA above is padding
+// and, once the hand-off loads were made contiguous, MFMA issue (2400-deep K) became the largest part of the
+// backward step.  In the 16-block form block kk (lanes 4kk..4kk+3) takes a DIFFERENT k, A = 4 units (one row
+// group), B = 4 batch columns: one instruction retires 16 k x 4 units x 4 batch columns with no padding beyond
+// rounding B up to a multiple of 4, at 10 cycles per instruction per wave with two waves per SIMD in flight
+// (tools/mfma4x4_probe.hip) against 32 for a 16x16x4.  Every block holds a partial sum over its own k: two DPP
+// row_shr adds fold them inside each 16-lane row (lanes 12-15 hold the row's sum) and the gate threads add the
+// remaining 4 rows x 8 waves from LDS.  k order: lane (kk, li) of wave w owns k = 64 G + 4 kk + e, G = w + 8 gi:
+// one dwordx4 feeds the four instructions e = 0..3, for A (weights, resident) and B (the exchange ring) alike.
+// Ring layout for this form: [dir][slot][batch quad][G][kk 16][4 batch rows][4 k] -- lane l of a wave-load reads
+// bytes 16 l .. 16 l + 15 of one contiguous KB.
+// ----------------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ float dpp_row_shr_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+
+constexpr int CGC = 4;   // batch quads per chunk = 16 batch columns
+
+template <int NGI>
+__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                       const float* __restrict__ hout,
+                                                                       const float* __restrict__ d_out,
+                                                                       const float* __restrict__ w_hh_t,
+                                                                       SyncWs* __restrict__ sync, float* __restrict__ ring,
+                                                                       int T, int B, int H, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float red4[];   // [wave][row 4][ (rg 2, cg, r 4, j 4) + pad ]
+    __shared__ int abort_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, nslice = gridDim.x;
+    const int j0 = blockIdx.x * PJU;
+    const int kk = lane >> 2, li = lane & 3;
+    const int K = 3 * H;
+    const int ncg = (B + 3) >> 2;
+    const int ng = (K + 63) >> 6;                       // 64-wide k groups
+    const int rs = 2 * ncg * 16 + 4;                    // floats per (wave, row) record
+    const int slot_floats = ncg * ng * 256;
+    if (tid == 0) abort_flag = 0;
+
+    f32x4 wA[2][NGI];                                   // weights of unit 4 rg + li at k = 64 G + 4 kk .. +3
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+        const int unit = j0 + 4 * rg + li;
+        const float* row = w_hh_t + ((size_t)dir * H + (unit < H ? unit : 0)) * K;
+#pragma unroll
+        for (int gi = 0; gi < NGI; ++gi) {
+            const int k = 64 * (wave + NWP * gi) + 4 * kk;
+            wA[rg][gi] = (unit < H && k < K) ? *reinterpret_cast<const f32x4*>(row + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const int jj = tid & 7, nn = (tid >> 3) & 15, gbt = tid >> 7;
+    const int gb = gbt * 16 + nn, gj = j0 + jj;
+    const bool gate_ok = (gb < B) && (gj < H);
+    float dhz = 0.f;
+    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? T - 1 - s : s;
+        const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
+        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
+        size_t row = 0, gbase = 0;
+        if (gate_ok) {
+            row = ((size_t)t * B + gb) * 2 + dir;
+            gbase = row * 3 * H + gj;
+            dh = d_out[((size_t)t * B + gb) * H + gj];
+            r = G[gbase];
+            z = G[gbase + H];
+            n = G[gbase + 2 * H];
+            gn = ghn[row * H + gj];
+            if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
+        }
+        if (s > 0) {
+            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+                abort_flag = 1;
+            __syncthreads();
+            if (abort_flag) return;
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
+            auto chunk = [&](int c, auto nci_tag) {
+                constexpr int NCI = decltype(nci_tag)::value;
+                f32x4 bf[NCI][NGI];
+#pragma unroll
+                for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                    for (int gi = 0; gi < NGI; ++gi) {
+                        const int g = wave + NWP * gi;             // wave-uniform; rows of padding batch entries are 0
+                        bf[ci][gi] = (g < ng) ? LOAD_HANDOFF(rs_x, (((c * CGC + ci) * ng + g) * 256 + lane * 4) * 4)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                f32x4 acc[2][NCI];
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int ci = 0; ci < NCI; ++ci) acc[rg][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int gi = 0; gi < NGI; ++gi)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int ci = 0; ci < NCI; ++ci) {
+                            acc[0][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[0][gi][e], bf[ci][gi][e], acc[0][ci], 0, 0, 0);
+                            acc[1][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[1][gi][e], bf[ci][gi][e], acc[1][ci], 0, 0, 0);
+                        }
+                // fold the 16 per-block partials: two DPP adds leave each 16-lane row's sum in its lanes 12..15
+                float* rec = red4 + (size_t)(wave * 4 + (lane >> 4)) * rs;
+#pragma unroll
+                for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+                    for (int ci = 0; ci < NCI; ++ci) {
+                        const int cg = c * CGC + ci;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            float v = acc[rg][ci][rr];
+                            v = dpp_row_shr_add<4>(v);
+                            v = dpp_row_shr_add<8>(v);
+                            if ((lane & 15) >= 12) rec[((rg * ncg + cg) * 4 + rr) * 4 + (lane & 3)] = v;
+                        }
+                    }
+            };
+            if (!(dbg & 2)) {
+                const int nfull = ncg / CGC, tail = ncg - nfull * CGC;
+#pragma unroll 1
+                for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGC>{});
+                if (tail == 1) chunk(nfull, std::integral_constant<int, 1>{});
+                else if (tail == 2) chunk(nfull, std::integral_constant<int, 2>{});
+                else if (tail == 3) chunk(nfull, std::integral_constant<int, 3>{});
+            }
+        }
+        __syncthreads();
+        if (gate_ok) {
+            if (s > 0) {
+                const int rg = jj >> 2, rr = jj & 3, cg = gb >> 2, bj = gb & 3;
+                const float* src = red4 + ((rg * ncg + cg) * 4 + rr) * 4 + bj;
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWP * 4; ++w) a += src[(size_t)w * rs];
+                dh += a + dhz;
+            }
+            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+            const float dz_pre = dh * (hpv - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * gn * r * (1.f - r);
+            dhz = dh * z;
+            {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
+                float* slot = ring + ((size_t)dir * 2 + (s & 1)) * slot_floats + (size_t)(gb >> 2) * ng * 256 + (gb & 3) * 4;
+                const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
+                store_sc1(&slot[(k0 >> 6) * 256 + ((k0 & 63) >> 2) * 16 + (k0 & 3)], dr_pre);
+                store_sc1(&slot[(k1 >> 6) * 256 + ((k1 & 63) >> 2) * 16 + (k1 & 3)], dz_pre);
+                store_sc1(&slot[(k2 >> 6) * 256 + ((k2 & 63) >> 2) * 16 + (k2 & 3)], dn_pre * r);
             }
             sv_r = dr_pre;
             sv_z = dz_pre;
@@ -395,6 +573,32 @@ bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float*
     return false;
 }
 
+bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
+                            SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
+    const int opts[] = {1, 2, 3, 5};
+    const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
+    dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
+    const int ncg = (B + 3) / 4;
+    const size_t lds = (size_t)NWP * 4 * (2 * ncg * 16 + 4) * sizeof(float);
+#define DS2_BWD4_CASE(K)                                                                                         \
+    case K:                                                                                                      \
+        if (lds > 64 * 1024 &&                                                                                   \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
+            return false;                                                                                        \
+        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t, sync, \
+                           ring, T, B, H, dbg);                                                                  \
+        return true;
+    switch (ngi) {
+        DS2_BWD4_CASE(1)
+        DS2_BWD4_CASE(2)
+        DS2_BWD4_CASE(3)
+        DS2_BWD4_CASE(5)
+    }
+#undef DS2_BWD4_CASE
+    return false;
+}
+
 inline bool persistent_ok(int B, int H) {
     return (H % 16 == 0) && (2 * ds2_cdiv(H, PJU) <= 240) && (B <= 64) && (ds2_cdiv(3 * H / 16, NWP) <= 19) &&
            (ds2_cdiv(H / 16, NWP) <= 7);
@@ -415,7 +619,11 @@ inline int dbg_flags() {
 // needs) was built and measured in round 1: correct, but 1.5x (forward) to 2.1x (backward) SLOWER per step than the
 // counter form -- 1600 waves polling payload lines swamp the fabric ("polling-cost" row of the price list).
 // exchange ring: [dir 2][slot 2][batch tiles][k blocks of 16][16][16] floats, sized for the backward pass (K = 3H)
-inline size_t ring_floats(int B, int H) { return (size_t)2 * 2 * ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256; }
+inline size_t ring_floats(int B, int H) {
+    const size_t a = (size_t)ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256;          // 16x16x4 forms
+    const size_t b = (size_t)ds2_cdiv(B, 4) * (size_t)ds2_cdiv(3 * H, 64) * 256;    // 4x4x1 backward form
+    return (size_t)2 * 2 * (a > b ? a : b);
+}
 
 extern "C" size_t ds2_gru_sync_ws_bytes(int B, int H) { return header_bytes() + ring_floats(B, H) * sizeof(float); }
 
@@ -460,7 +668,11 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     DS2_HIP(hipMemsetAsync(sync_ws, 0, header_bytes() + ring_floats(B, H) * sizeof(float), st));
     const int dbg = dbg_flags();
     bool ok;
-    if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    const char* form = getenv("DS2_GRU_BWD");   // "16" selects the 16x16x4 MFMA form (A/B timing); default: 4x4x1
+    const bool use4 = form ? form[0] == '4' : true;
+    if (use4 && ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5)
+        ok = launch_bwd_persistent4(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     DS2_CHECK_ARG(ok);

@@ -269,7 +269,7 @@ def main():
                    'last_loss': round(float(loss), 4),
                    'inference_frames_per_s_rank0': round(inf_frames / inf_dt, 1)},
         'roofline': {'bound': 'mfma',
-                     'kernel': 'gru_bwd_persistent_kernel (one launch = all T=%d steps of a BiGRU layer, both '
+                     'kernel': 'gru_bwd_persistent4_kernel (one launch = all T=%d steps of a BiGRU layer, both '
                                'directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic,
