@@ -43,12 +43,10 @@ __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int 
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */);
     return __builtin_bit_cast(f32x4, v);
 }
-__device__ __forceinline__ f32x4 load_plain_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
-    return __builtin_bit_cast(f32x4, v);
-}
-// hand-off payload load: dbg bit 5 (32) = timing experiment with plain (L2-allocating) loads
-#define LOAD_HANDOFF(rs, off) ((dbg & 32) ? load_plain_b128(rs, off) : load_sc1_b128(rs, off))
+// hand-off payload load (a timing experiment with plain, L2-allocating loads showed no difference; a run-time
+// switch between the two forms here costs a branch and a vmcnt(0) join in front of the MFMAs)
+#define LOAD_HANDOFF(rs, off) load_sc1_b128(rs, off)
+constexpr int OOB_OFFSET = 0x7FFFFFF0;    // beyond any descriptor's num_records: the range-checked load returns 0
 __device__ __forceinline__ void store_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -148,8 +146,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
                 for (int i = 0; i < KBW; ++i) {
                     const int kb = wave + NWP * i;                 // wave-uniform
                     // rows of padding batch entries are never written and stay zero (the ring is zeroed per launch)
-                    dst[i] = (kb < nkb) ? LOAD_HANDOFF(rsrc, ((bt * nkb + kb) * 256 + lane * 4) * 4)
-                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+                    // k blocks past the end: an offset beyond the descriptor's range reads as zero, with no branch
+                    dst[i] = LOAD_HANDOFF(rsrc, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
                 }
             };
             if (!(dbg & 2)) {
@@ -288,8 +286,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
                 for (int c = 0; c < CH; ++c) {
                     const int i = i0 + c;
                     const int kb = wave + NWP * i;                 // wave-uniform
-                    dst[c] = (i < KBW && kb < nkb) ? LOAD_HANDOFF(rs_x, ((bt * nkb + kb) * 256 + lane * 4) * 4)
-                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (i < KBW)                                   // compile-time
+                        dst[c] = LOAD_HANDOFF(rs_x, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
+                    else
+                        dst[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
             if (!(dbg & 2)) {
@@ -372,6 +372,7 @@ __device__ __forceinline__ float dpp_row_shr_add(float v) {
 }
 
 constexpr int CGC = 4;   // batch quads per chunk = 16 batch columns
+constexpr int RED4_PITCH = NWP * 4 + 4;   // floats per reduced value in LDS: 32 partials + 4 (bank spread, keeps 16-B alignment)
 
 template <int NGI>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
@@ -380,7 +381,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                                                                        const float* __restrict__ w_hh_t,
                                                                        SyncWs* __restrict__ sync, float* __restrict__ ring,
                                                                        int T, int B, int H, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) float red4[];   // [wave][row 4][ (rg 2, cg, r 4, j 4) + pad ]
+    // [value = (rg 2, cg, r 4, j 4)][RED4_PITCH: partial = wave * 4 + lane row]: a gate thread's 32 partials are
+    // contiguous (eight ds_read_b128 in flight; as 32 scalar reads the compiler chained read -> wait -> add, ~0.6 us
+    // per step), and the pitch of 36 puts the 16 storing lanes of a fold (4 rows x 4 j) on 16 different banks
+    extern __shared__ __attribute__((aligned(16))) float red4[];
     __shared__ int abort_flag;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -391,7 +395,6 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     const int K = 3 * H;
     const int ncg = (B + 3) >> 2;
     const int ng = (K + 63) >> 6;                       // 64-wide k groups
-    const int rs = 2 * ncg * 16 + 4;                    // floats per (wave, row) record
     const int slot_floats = ncg * ng * 256;
     if (tid == 0) abort_flag = 0;
 
@@ -440,13 +443,15 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 constexpr int NCI = decltype(nci_tag)::value;
                 f32x4 bf[NCI][NGI];
 #pragma unroll
-                for (int ci = 0; ci < NCI; ++ci)
+                for (int gi = 0; gi < NGI; ++gi)                   // k-group major: the MFMAs below consume in this order
 #pragma unroll
-                    for (int gi = 0; gi < NGI; ++gi) {
+                    for (int ci = 0; ci < NCI; ++ci) {
                         const int g = wave + NWP * gi;             // wave-uniform; rows of padding batch entries are 0
-                        bf[ci][gi] = (g < ng) ? LOAD_HANDOFF(rs_x, (((c * CGC + ci) * ng + g) * 256 + lane * 4) * 4)
-                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (g < ng) ? (((c * CGC + ci) * ng + g) * 256 + lane * 4) * 4 : OOB_OFFSET);
                     }
+                // every load of the chunk goes out before the first MFMA: left alone the scheduler sinks loads in between
+                // the MFMAs and keeps only 2-5 in flight, which throttles a phase bounded by bytes in flight
+                __builtin_amdgcn_sched_barrier(0);
                 f32x4 acc[2][NCI];
 #pragma unroll
                 for (int rg = 0; rg < 2; ++rg)
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                             acc[1][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[1][gi][e], bf[ci][gi][e], acc[1][ci], 0, 0, 0);
                         }
                 // fold the 16 per-block partials: two DPP adds leave each 16-lane row's sum in its lanes 12..15
-                float* rec = red4 + (size_t)(wave * 4 + (lane >> 4)) * rs;
+                float* rec = red4 + (lane & 3) * RED4_PITCH + wave * 4 + (lane >> 4);
 #pragma unroll
                 for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                             float v = acc[rg][ci][rr];
                             v = dpp_row_shr_add<4>(v);
                             v = dpp_row_shr_add<8>(v);
-                            if ((lane & 15) >= 12) rec[((rg * ncg + cg) * 4 + rr) * 4 + (lane & 3)] = v;
+                            if ((lane & 15) >= 12) rec[((rg * ncg + cg) * 4 + rr) * 4 * RED4_PITCH] = v;
                         }
                     }
             };
@@ -490,11 +495,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         if (gate_ok) {
             if (s > 0) {
                 const int rg = jj >> 2, rr = jj & 3, cg = gb >> 2, bj = gb & 3;
-                const float* src = red4 + ((rg * ncg + cg) * 4 + rr) * 4 + bj;
-                float a = 0.f;
+                const f32x4* src = reinterpret_cast<const f32x4*>(red4 + (((rg * ncg + cg) * 4 + rr) * 4 + bj) * RED4_PITCH);
+                f32x4 p[NWP];
 #pragma unroll
-                for (int w = 0; w < NWP * 4; ++w) a += src[(size_t)w * rs];
-                dh += a + dhz;
+                for (int w = 0; w < NWP; ++w) p[w] = src[w];
+                const f32x4 q = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                dh += ((q[0] + q[1]) + (q[2] + q[3])) + dhz;
             }
             const float dn_pre = dh * (1.f - z) * (1.f - n * n);
             const float dz_pre = dh * (hpv - n) * z * (1.f - z);
@@ -579,7 +585,7 @@ bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float
     const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
     dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
     const int ncg = (B + 3) / 4;
-    const size_t lds = (size_t)NWP * 4 * (2 * ncg * 16 + 4) * sizeof(float);
+    const size_t lds = (size_t)2 * ncg * 16 * RED4_PITCH * sizeof(float);
 #define DS2_BWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
