@@ -155,6 +155,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
 #pragma unroll
                 for (int bt = 0; bt < NBT; ++bt) {
                     if (bt + 1 < NBT) fetch(bt + 1, bf[(bt + 1) & 1]);
+                    // all loads out before the MFMAs (the scheduler would otherwise sink them in between, 2 in flight)
+                    __builtin_amdgcn_sched_barrier(0);
                     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
                     for (int i = 0; i < KBW; ++i)
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
 #pragma unroll
                 for (int st = 0; st < NST; ++st) {
                     if (st + 1 < NST) fetch(st + 1, bf[(st + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);   // loads out before the MFMAs
                     const int bt = st / NCH, i0 = (st % NCH) * CH;
 #pragma unroll
                     for (int c = 0; c < CH; ++c)
