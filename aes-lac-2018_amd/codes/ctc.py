@@ -18,7 +18,7 @@ def ctc_costs_and_grad(acts, labels, act_lens, label_lens, grad_scale=1.0):
     """Raw kernel call: returns (costs (B,), grad (T,B,A)) on the device of ``acts``.
 
     The four small integer arrays the warp-ctc signature passes on the host (labels, lengths) travel to the
-    device in ONE pinned upload."""
+    device in ONE upload through a reusable pinned staging buffer."""
     dev = acts.device
     label_lens_c = torch.as_tensor(label_lens).to('cpu', torch.int32).reshape(-1)
     act_lens_c = torch.as_tensor(act_lens).to('cpu', torch.int32).reshape(-1)
@@ -26,13 +26,13 @@ def ctc_costs_and_grad(acts, labels, act_lens, label_lens, grad_scale=1.0):
     bsz = label_lens_c.numel()
     max_len = int(label_lens_c.max().item()) if bsz else 0
     nlab = max(int(labels_c.numel()), 1)
-    packed = torch.zeros(nlab + 3 * bsz, dtype=torch.int32).pin_memory()
+    packed = torch.zeros(nlab + 3 * bsz, dtype=torch.int32)
     packed[:labels_c.numel()] = labels_c
     if bsz > 1:
         packed[nlab + 1:nlab + bsz] = torch.cumsum(label_lens_c, 0)[:-1]          # start of each utterance's labels
     packed[nlab + bsz:nlab + 2 * bsz] = label_lens_c
     packed[nlab + 2 * bsz:] = act_lens_c
-    d = packed.to(dev, non_blocking=True)
+    d = ops.upload_small(packed, dev)
     return ops.ctc_loss_grad(acts.contiguous().float(), d[:nlab], d[nlab:nlab + bsz], d[nlab + bsz:nlab + 2 * bsz],
                              d[nlab + 2 * bsz:], max_len, grad_scale)
 

@@ -92,7 +92,8 @@ class Trainer(object):
             self.skip_n -= 1
             return 'Skipped'
         model = self.model
-        model.train()
+        if not model.training:
+            model.train()
         t0 = time.time()
         inputs, targets, input_percentages, target_sizes = batch
         if self.frontend is not None and isinstance(inputs, (list, tuple)):
@@ -126,8 +127,9 @@ class Trainer(object):
         # one device->host readback for everything the host needs: loss, grad norm^2, kernel timeout flags
         words = ops.async_error_words()
         stats = torch.cat([costs.sum().double().reshape(1) / bsz, self._sumsq] + [w.double() for w in words])
-        torch.cuda.synchronize()                                          # codes/engine.py:92
-        stats = stats.tolist()
+        host, done = ops.download_small(stats)                            # async copy into pinned memory
+        ops.spin_wait(done)                                               # the step's one sync (codes/engine.py:92)
+        stats = host.tolist()
         if any(v != 0 for v in stats[2:]):
             ops.raise_async_error()
         self.iteration += 1

@@ -246,7 +246,10 @@ class DeepSpeech(nn.Module):
         # fine-tuning with frozen conv layers keeps their BatchNorm in inference mode (training_utils.py:52-54,73)
         conv_frozen = getattr(c[1], 'frozen_stats', False) or getattr(c[4], 'frozen_stats', False)
         conv_train = training and not conv_frozen
-        for mod in list(self.rnns.modules()) + list(self.fc.modules()):
+        mods = self.__dict__.get('_bn_walk')
+        if mods is None:                                   # the module tree is static: walk it once
+            mods = self.__dict__['_bn_walk'] = list(self.rnns.modules()) + list(self.fc.modules())
+        for mod in mods:
             if getattr(mod, 'frozen_stats', False):
                 raise NotImplementedError('freezing BatchNorm statistics is supported for the conv block only')
         xt = ops.transpose_btf(x)                                                   # (B,161,T_in)

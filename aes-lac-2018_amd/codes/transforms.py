@@ -73,7 +73,7 @@ class BatchSpectrogram(object):
             offs.append(offs[-1] + n)
         frames = [1 + n // HOP for n in lens]
         t_max = max(frames)
-        offs_d = torch.tensor(offs, dtype=torch.int64).pin_memory().to(flat.device, non_blocking=True)
+        offs_d = ops.upload_small(torch.tensor(offs, dtype=torch.int64), flat.device)
         inputs = ops.spectrogram(flat, offs_d, t_max, self.normalize, self.eps)
         pct = torch.tensor([f / float(t_max) for f in frames], dtype=torch.float32)
         return inputs, pct

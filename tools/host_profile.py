@@ -1,0 +1,62 @@
+"""Host-side profile of the training step (where does the CPU spend the time between GPU kernels?)."""
+import cProfile, pstats, sys, os, time, io
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'aes-lac-2018_amd'))
+import numpy as np, torch
+import bench
+from codes.engine import Trainer
+from codes.model import DeepSpeech
+from codes.transforms import BatchSpectrogram
+dev = torch.device('cuda', 0)
+plan = bench.bin_plan(10, bench.NUM_BINS, world=1)
+mine = [bench.make_bin(p) for p in plan]
+resident = []
+for wavs, labels, lens in mine:
+    flat = torch.from_numpy(np.concatenate(wavs)).to(dev)
+    offs = np.concatenate([[0], np.cumsum([len(w) for w in wavs])]).astype(np.int64)
+    resident.append((flat, offs, torch.from_numpy(labels), torch.from_numpy(lens)))
+torch.manual_seed(42)
+model = DeepSpeech().to(dev)
+opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
+trainer = Trainer(model, opt, device=dev, max_norm=400)
+front = BatchSpectrogram(device=dev)
+def step(i):
+    flat, offs, labels, lens = resident[i % len(resident)]
+    inputs, pct = front(flat, offs)
+    return trainer.update((inputs, labels, pct, lens))
+for i in range(6): step(i)
+torch.cuda.synchronize()
+# host time until everything is enqueued vs total
+import codes.engine as eng
+orig_sync = torch.cuda.synchronize
+enq = []
+def sync_timed():
+    enq.append(time.perf_counter()); orig_sync()
+torch.cuda.synchronize = sync_timed
+t_start = []
+for i in range(6, 30):
+    t_start.append(time.perf_counter()); step(i)
+torch.cuda.synchronize = orig_sync
+t_end = t_start[1:] + [time.perf_counter()]
+print('host enqueue time per step (ms): mean %.2f; step total mean %.2f' % (
+    1e3 * np.mean([e - s for s, e in zip(t_start, enq)]), 1e3 * np.mean([e - s for s, e in zip(t_start, t_end)])))
+pr = cProfile.Profile(); pr.enable()
+for i in range(30, 54): step(i)
+pr.disable()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(28); print(s.getvalue()[:6000])
+
+# ---- host timeline of one step: when is each C-ABI call issued (ms since step start)?
+from ds2hip import lib as _lib
+rec = []
+_orig = _lib.call
+def _call(name, *a, **k):
+    rec.append((time.perf_counter(), name)); return _orig(name, *a, **k)
+_lib.call = _call
+import ds2hip.ops as _ops
+if hasattr(_ops, 'call'): _ops.call = _call
+if hasattr(_ops, 'lib'): _ops.lib.call = _call
+torch.cuda.synchronize(); t0 = time.perf_counter(); step(60); t1 = time.perf_counter()
+print('step wall %.2f ms, %d calls' % (1e3 * (t1 - t0), len(rec)))
+prev = t0
+for t, n in rec[:40]:
+    print('%7.3f (+%.3f) %s' % (1e3 * (t - t0), 1e3 * (t - prev), n)); prev = t
