@@ -365,8 +365,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
 // row_shr adds fold them inside each 16-lane row (lanes 12-15 hold the row's sum) and the gate threads add the
 // remaining 4 rows x 8 waves from LDS.  k order: lane (kk, li) of wave w owns k = 64 G + 4 kk + e, G = w + 8 gi:
 // one dwordx4 feeds the four instructions e = 0..3, for A (weights, resident) and B (the exchange ring) alike.
-// Ring layout for this form: [dir][slot][batch quad][G][kk 16][4 batch rows][4 k] -- lane l of a wave-load reads
-// bytes 16 l .. 16 l + 15 of one contiguous KB.
+// Ring layout for this form: [dir][slot][batch quad][G][kk 16][batch rows of the quad][4 k] -- lane l of a
+// wave-load reads bytes 16 l .. 16 l + 15 of one contiguous KB; a partial last quad (B & 3 rows) is stored compactly
+// and the lanes of its missing rows load nothing (B = 10: 96 KB per workgroup per step instead of 115).
 // ----------------------------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ float dpp_row_shr_add(float v) {
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     const int K = 3 * H;
     const int ncg = (B + 3) >> 2;
     const int ng = (K + 63) >> 6;                       // 64-wide k groups
-    const int slot_floats = ncg * ng * 256;
+    const int slot_floats = ng * 64 * B;                // a partial last quad keeps only its B & 3 rows
     if (tid == 0) abort_flag = 0;
 
     f32x4 wA[2][NGI];                                   // weights of unit 4 rg + li at k = 64 G + 4 kk .. +3
@@ -449,8 +450,13 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 for (int gi = 0; gi < NGI; ++gi)                   // k-group major: the MFMAs below consume in this order
 #pragma unroll
                     for (int ci = 0; ci < NCI; ++ci) {
-                        const int g = wave + NWP * gi;             // wave-uniform; rows of padding batch entries are 0
-                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (g < ng) ? (((c * CGC + ci) * ng + g) * 256 + lane * 4) * 4 : OOB_OFFSET);
+                        const int g = wave + NWP * gi;             // wave-uniform
+                        const int cg = c * CGC + ci;
+                        const int rows = min(4, B - 4 * cg);       // batch rows this quad really has
+                        // lanes of rows past the batch (and k groups past K) read nothing: out-of-range offset -> 0
+                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (g < ng && li < rows)
+                                                            ? (cg * ng * 256 + ((g * 16 + kk) * rows + li) * 4) * 4
+                                                            : OOB_OFFSET);
                     }
                 // every load of the chunk goes out before the first MFMA: left alone the scheduler sinks loads in between
                 // the MFMAs and keeps only 2-5 in flight, which throttles a phase bounded by bytes in flight
@@ -510,11 +516,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             const float dr_pre = dn_pre * gn * r * (1.f - r);
             dhz = dh * z;
             {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
+                const int rows4 = min(4, B - (gb & ~3)) * 4;   // floats per (k quad) of this batch quad
                 float* slot = ring + ((size_t)dir * 2 + (s & 1)) * slot_floats + (size_t)(gb >> 2) * ng * 256 + (gb & 3) * 4;
                 const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
-                store_sc1(&slot[(k0 >> 6) * 256 + ((k0 & 63) >> 2) * 16 + (k0 & 3)], dr_pre);
-                store_sc1(&slot[(k1 >> 6) * 256 + ((k1 & 63) >> 2) * 16 + (k1 & 3)], dz_pre);
-                store_sc1(&slot[(k2 >> 6) * 256 + ((k2 & 63) >> 2) * 16 + (k2 & 3)], dn_pre * r);
+                store_sc1(&slot[(k0 >> 2) * rows4 + (k0 & 3)], dr_pre);
+                store_sc1(&slot[(k1 >> 2) * rows4 + (k1 & 3)], dz_pre);
+                store_sc1(&slot[(k2 >> 2) * rows4 + (k2 & 3)], dn_pre * r);
             }
             sv_r = dr_pre;
             sv_z = dz_pre;
@@ -630,7 +637,7 @@ inline int dbg_flags() {
 // exchange ring: [dir 2][slot 2][batch tiles][k blocks of 16][16][16] floats, sized for the backward pass (K = 3H)
 inline size_t ring_floats(int B, int H) {
     const size_t a = (size_t)ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256;          // 16x16x4 forms
-    const size_t b = (size_t)ds2_cdiv(B, 4) * (size_t)ds2_cdiv(3 * H, 64) * 256;    // 4x4x1 backward form
+    const size_t b = (size_t)B * (size_t)ds2_cdiv(3 * H, 64) * 64;                  // 4x4x1 backward form
     return (size_t)2 * 2 * (a > b ? a : b);
 }
 
