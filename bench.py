@@ -254,7 +254,7 @@ def main():
     try:
         rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
         if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
-            traffic = rec['gru_bwd_persistent_kernel']['traffic_bytes_per_launch']
+            traffic = rec['gru_bwd_persistent4_kernel']['traffic_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         pass
     result = {

@@ -1,5 +1,6 @@
 import os, sys, subprocess, json
-sys.path.insert(0, 'aes-lac-2018_amd'); sys.path.insert(0, '.')
+_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, os.path.join(_ROOT, 'aes-lac-2018_amd')); sys.path.insert(0, _ROOT)
 import torch, numpy as np
 from ds2hip import ops
 t, bsz, hid = 405, int(os.environ.get('BSZ', '10')), 800
