@@ -4,31 +4,24 @@
 (``[[str]]`` and ``[[IntTensor]]``, ``codes/decoder.py:99-160``).  The argmax over the alphabet and the
 collapse (drop blank; drop a symbol equal to the previous FRAME's symbol) run on the GPU
 (``ds2_argmax_rows`` + ``ds2_greedy_collapse``); only the compacted ids cross to the host to become strings.
-Edit distance replaces python-Levenshtein (absent here) with a two-row dynamic programme.
+Edit distance replaces python-Levenshtein (absent here) with ``ds2_edit_distance`` (host C++ in libds2hip.so).
+``BeamCTCDecoder`` (CTC prefix beam search, ``ds2_ctc_beam_search``) is an addition: the reference's ``test.py:21``
+offers greedy / none only.
 """
 import numpy as np
 import torch
 
-from ds2hip import ops
+from ds2hip import lib, ops
 
 from .preprocessing import OrderedLabelEncoder
 
 
 def _levenshtein(a, b):
-    if len(a) < len(b):
-        a, b = b, a
-    if len(b) == 0:
-        return len(a)
-    prev = np.arange(len(b) + 1)
-    bb = np.asarray([hash(c) for c in b])
-    for i, ca in enumerate(a, 1):
-        sub = prev[:-1] + (bb != hash(ca))
-        cur = np.minimum(prev[1:] + 1, sub)
-        cur = np.concatenate(([i], cur))
-        # horizontal dependency (insertions): cur[j] = min(cur[j], cur[j-1] + 1)
-        cur = np.minimum.accumulate(cur - np.arange(len(cur))) + np.arange(len(cur))
-        prev = cur
-    return int(prev[-1])
+    """Edit distance of two sequences of hashable items (``ds2_edit_distance``, host C++)."""
+    ids = {}
+    ia = np.asarray([ids.setdefault(x, len(ids)) for x in a], dtype=np.int32)
+    ib = np.asarray([ids.setdefault(x, len(ids)) for x in b], dtype=np.int32)
+    return lib.host_call('ds2_edit_distance', ia, len(ia), ib, len(ib))
 
 
 class Decoder(object):
@@ -92,4 +85,36 @@ class GreedyDecoder(Decoder):
         ids, offs, lens = ids.cpu().numpy(), offs.cpu().numpy(), lens.cpu().numpy()
         strings = [[self._to_string(ids[b, :lens[b]])] for b in range(bsz)]
         offsets = [[torch.IntTensor(offs[b, :lens[b]].copy())] for b in range(bsz)]
+        return strings, offsets
+
+
+class BeamCTCDecoder(GreedyDecoder):
+    """CTC prefix beam search without a language model (not in the reference).
+
+    ``decode(probs (B,T,A), sizes)`` returns the same ``([[str]], [[IntTensor offsets]])`` shape as the greedy
+    decoder; the probabilities cross to the host once and the search runs in ``ds2_ctc_beam_search``.
+    ``log_input=True`` if ``probs`` are log-probabilities."""
+
+    def __init__(self, label_encoder, blank_index=0, beam_width=16, log_input=False):
+        super().__init__(label_encoder, blank_index)
+        if beam_width < 1:
+            raise ValueError('beam_width must be >= 1')
+        self.beam_width, self.log_input = int(beam_width), bool(log_input)
+        self.last_log_probs = None
+
+    def decode(self, probs, sizes=None):
+        import ctypes
+        host = np.ascontiguousarray(torch.as_tensor(probs).detach().float().cpu().numpy())
+        bsz, t, a = host.shape
+        strings, offsets, scores = [], [], []
+        for b in range(bsz):
+            n = int(sizes[b]) if sizes is not None else t
+            ids, offs = np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int32)
+            length, logp = ctypes.c_int(0), ctypes.c_float(0.0)
+            lib.host_call('ds2_ctc_beam_search', host[b, :n], n, a, self.blank_index, self.beam_width,
+                          int(self.log_input), ids, offs, len(ids), length, logp)
+            strings.append([self._to_string(ids[:length.value])])
+            offsets.append([torch.IntTensor(offs[:length.value].copy())])
+            scores.append(logp.value)
+        self.last_log_probs = scores
         return strings, offsets

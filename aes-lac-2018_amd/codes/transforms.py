@@ -126,7 +126,11 @@ class ToLabel(object):
 
     Upper-cases, optionally folds accents (a fixed Latin-1 table stands in for ``unidecode``), drops every
     character that is not in the label set.  Number-to-words conversion (``num2words``, absent here) is NOT
-    applied: digits are simply not in the alphabets and get filtered -- a documented deviation."""
+    applied.  In the reference the conversion runs AFTER upper-casing (``codes/transforms.py:370-376``) and
+    num2words writes lower-case words, so with the upper-case alphabets of ``data/labels.*.json`` every letter
+    of the spelled-out number is filtered again and only the spaces between its words survive: "I HAVE 2 DOGS"
+    becomes "I HAVE  DOGS" there and here alike; a multi-word number ("1,234") leaves a few more spaces in the
+    reference than here -- a documented deviation (LibriSpeech transcripts contain no digits)."""
 
     def __init__(self, labels='labels.en.json', to_upper=True, one_hot=False, convert_number_to_words=True, lang=None,
                  remove_accents=True, dtype=None):

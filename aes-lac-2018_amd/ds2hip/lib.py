@@ -53,6 +53,8 @@ SIGNATURES = {
     'ds2_sumsq': (_I, [_P, _Z, _P, _P, _P]),
     'ds2_clip_sgd_nesterov': (_I, [_P, _P, _P, _Z, _P, _F, _F, _F, _F, _I, _P]),
     'ds2_add2': (_I, [_P, _P, _Z, _P, _P]),
+    'ds2_edit_distance': (_I, [_P, _I, _P, _I]),
+    'ds2_ctc_beam_search': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
 }
 
 _lib = None
@@ -102,6 +104,26 @@ def call(name, *args):
               for a in args], torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise RuntimeError('%s failed (%d): %s' % (name, rc, load().ds2_last_error().decode()))
+
+
+def host_call(name, *args):
+    """Invoke a HOST entry point (numpy arrays / ctypes objects in, no stream); returns its int result, raising on a
+    negative one."""
+    import numpy as np
+    conv = []
+    for a in args:
+        if isinstance(a, np.ndarray):
+            if not a.flags['C_CONTIGUOUS']:
+                raise RuntimeError('host entry points take C-contiguous arrays')
+            conv.append(a.ctypes.data)
+        elif isinstance(a, (ctypes.c_int, ctypes.c_float)):
+            conv.append(ctypes.addressof(a))
+        else:
+            conv.append(a)
+    rc = getattr(load(), name)(*conv)
+    if rc < 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, load().ds2_last_error().decode()))
+    return rc
 
 
 def query(name, *args):

@@ -166,6 +166,18 @@ int ds2_argmax_rows(const float* x, int rows, int A, int32_t* idx, void* stream)
 int ds2_greedy_collapse(const int32_t* best, const int32_t* sizes, int B, int T, int blank,
                         int32_t* out_ids, int32_t* out_offsets, int32_t* out_lens, void* stream);
 
+/* ------------------------------------------------------------------ host-side scoring / decoding helpers
+ * HOST pointers, no stream.
+ * ds2_edit_distance: Levenshtein distance of two int32 sequences (>= 0; negative = error).  Replaces the
+ *   python-Levenshtein calls under Decoder.wer / Decoder.cer (codes/decoder.py:20,49-78).
+ * ds2_ctc_beam_search: CTC prefix beam search over ONE utterance's (T, A) probabilities (log_input = 0) or
+ *   log-probabilities (log_input = 1); writes the best labelling (<= out_cap labels), the frame each label first
+ *   appeared at, its length and log-probability.  Not in the reference (test.py:21 offers greedy / none only);
+ *   SURVEY.md 8f rank 4. */
+int ds2_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
+int ds2_ctc_beam_search(const float* probs, int T, int A, int blank, int beam_width, int log_input,
+                        int32_t* out_labels, int32_t* out_offsets, int out_cap, int* out_len, float* out_logp);
+
 /* ------------------------------------------------------------------ CTC
  * Replaces warpctc_pytorch.CTCLoss (train.py:179, codes/engine.py:22, codes/metrics.py:51):
  * softmax over A inside, blank 0, costs[b] = -log p(labels_b | acts[:act_lens[b], b]),

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'aes-lac-2018_amd'))
 
 from codes.data import AudioDataLoader, AudioDataset  # noqa: E402
-from codes.decoder import GreedyDecoder  # noqa: E402
+from codes.decoder import BeamCTCDecoder, GreedyDecoder  # noqa: E402
 from codes.transforms import BatchSpectrogram  # noqa: E402
 from codes.utils.model_utils import load_model  # noqa: E402
 
@@ -25,7 +25,9 @@ def main(argv=None):
     p.add_argument('--manifest', metavar='DIR', default='data/test_manifest.csv')
     p.add_argument('--batch-size', default=32, type=int)
     p.add_argument('--num-workers', default=4, type=int)
-    p.add_argument('--decoder', default='greedy', choices=['greedy', 'none'], type=str)
+    p.add_argument('--decoder', default='greedy', choices=['greedy', 'beam', 'none'], type=str,
+                   help="'beam' (CTC prefix beam search, no LM) is an addition to the reference's greedy / none")
+    p.add_argument('--beam-width', default=16, type=int)
     p.add_argument('--verbose', action='store_true')
     p.add_argument('--output-path', default=None, type=str)
     args = p.parse_args(argv)
@@ -34,7 +36,9 @@ def main(argv=None):
     model, _, val_t, target_t = load_model(args.model_path, return_transforms=True, data_dir=args.data_dir)
     model.eval().to('cuda')
     target_t = target_t[0]
-    decoder = GreedyDecoder(target_t.label_encoder) if args.decoder == 'greedy' else None
+    decoder = {'greedy': lambda: GreedyDecoder(target_t.label_encoder),
+               'beam': lambda: BeamCTCDecoder(target_t.label_encoder, beam_width=args.beam_width),
+               'none': lambda: None}[args.decoder]()
     target_decoder = GreedyDecoder(target_t.label_encoder)
     dataset = AudioDataset(args.data_dir, args.manifest, transforms=val_t, target_transforms=target_t)
     loader = AudioDataLoader(dataset, batch_size=args.batch_size, num_workers=args.num_workers, raw_audio=True)

@@ -55,6 +55,12 @@ def test_train_then_test_cli(tmp_path):
                           '0', '--cuda'], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert 'Test Summary' in out.stdout and 'Average CER' in out.stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'test.py'), '--model-path', str(ckpt), '--data-dir',
+                          str(tmp_path), '--manifest', str(tmp_path / 'val.csv'), '--batch-size', '2', '--num-workers',
+                          '0', '--decoder', 'beam', '--beam-width', '8'], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert 'Test Summary' in out.stdout and 'Average CER' in out.stdout
 
 
 def test_train_cli_distributed_launch(tmp_path):

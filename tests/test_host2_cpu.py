@@ -120,6 +120,44 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(v, again.state_dict()[k])
 
 
+def test_older_checkpoint_formats(tmp_path):
+    """The two older payloads the reference still reads (model_utils.py:26-54 and :80-124)."""
+    from codes.model import DeepSpeech
+    from codes.utils import model_utils as mu
+    # (1) version 0.0.1: geometry in seconds, inline labels, stray BatchNorm keys on the first recurrent layer
+    labels = "_'ABCDEFGHIJKLMNOPQRSTUVWXYZ "
+    model = DeepSpeech(rnn_hidden_size=32, num_rnn_layers=2, num_classes=len(labels))
+    sd = dict(model.state_dict())
+    for leaf in ('weight', 'bias', 'running_mean', 'running_var'):
+        sd['rnns.0.batch_norm.module.' + leaf] = torch.zeros(3)
+    legacy = {'version': '0.0.1', 'audio_conf': {'sample_rate': 16000, 'window_size': 0.02, 'window_stride': 0.01},
+              'hidden_size': 32, 'hidden_layers': 2, 'rnn_type': 'gru', 'labels': labels, 'bidirectional': True,
+              'state_dict': sd}
+    path = str(tmp_path / 'legacy.pth')
+    torch.save(legacy, path)
+    again, front, to_label = mu.load_model(path)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, again.state_dict()[k])
+    assert again._num_classes == 29 and len(front.transforms) == 2
+    assert to_label('ab c').reshape(-1).tolist() == [2, 3, 28, 4]
+    # (2) current payload whose args.config is still in the network/transforms schema
+    old_cfg = {'network': {'name': 'deepspeech', 'params': {'rnn_hidden_size': 32, 'num_rnn_layers': 2}},
+               'transforms': {'label': [{'params': {'labels': '{data_dir}/labels.en.json'}}],
+                              'train': [{'params': {'augment': False}}]},
+               'training': {'num_epochs': 7, 'max_norm': 400, 'learning_rate': 3e-4, 'momentum': 0.9,
+                            'learning_anneal': 0.99}}
+    ckpt = {'args': {'data_dir': os.path.join(ROOT, 'data'), 'batch_size': 10, 'finetune': False, 'config': old_cfg},
+            'state_dict': model.state_dict()}
+    path2 = str(tmp_path / 'old_schema.pth')
+    torch.save(ckpt, path2)
+    m2, back = mu.load_model(path2, return_ckpt=True)
+    assert torch.equal(m2.state_dict()['fc.0.module.1.weight'], model.state_dict()['fc.0.module.1.weight'])
+    from codes.utils.io_utils import AttrDict
+    up = mu.upgrade_config(AttrDict(ckpt['args'])).config
+    assert up.model.langs == ['en'] and up.model.params.num_classes == 29 and up.training.batch_size == 10
+    assert up.optimizer.params.nesterov is True and up.scheduler.params.gamma == 0.99 and up.training.num_epochs == 7
+
+
 def _ddp_worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -165,3 +203,76 @@ def test_two_rank_gloo_partition_and_bucketed_allreduce():
     got = sorted(out.get(timeout=10) for _ in range(2))
     assert got[0][1] == got[1][1] == 3                 # ceil(6 bins / 2 ranks)
     assert got[0][2] == got[1][2]                      # parameters identical after the rank-0 broadcast
+
+
+# ------------------------------------------------------------------------------------------- host C++ helpers
+def _py_edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def test_edit_distance_host_entry_point():
+    from codes.decoder import Decoder, _levenshtein
+    rng = np.random.default_rng(3)
+    assert _levenshtein('', '') == 0 and _levenshtein('abc', '') == 3 and _levenshtein('', 'xy') == 2
+    assert _levenshtein('kitten', 'sitting') == 3
+    for _ in range(200):
+        a = ''.join(rng.choice(list('abcd '), size=rng.integers(0, 30)))
+        b = ''.join(rng.choice(list('abcd '), size=rng.integers(0, 30)))
+        assert _levenshtein(a, b) == _py_edit_distance(a, b)
+    d = Decoder("_'ABCDEFGHIJKLMNOPQRSTUVWXYZ ")
+    assert d.wer('THE CAT SAT', 'THE CAT SAT DOWN') == 1 and d.wer('A B C', 'C B A') == 2
+    assert d.cer('HE LLO', 'HELLO') == 0 and d.cer('HELLO', 'HALLO W') == 2
+
+
+def _best_labelling_by_enumeration(probs, blank=0):
+    """Exact most probable labelling of a tiny (T, A) CTC output: sum the path probabilities per collapsed string."""
+    import itertools
+    t, a = probs.shape
+    table = {}
+    for path in itertools.product(range(a), repeat=t):
+        p = float(np.prod([probs[i, c] for i, c in enumerate(path)]))
+        lab, prev = [], None
+        for c in path:
+            if c != blank and c != prev:
+                lab.append(c)
+            prev = c
+        table[tuple(lab)] = table.get(tuple(lab), 0.0) + p
+    best = max(table.items(), key=lambda kv: kv[1])
+    return list(best[0]), best[1]
+
+
+def test_ctc_prefix_beam_search_host_entry_point():
+    from codes.decoder import BeamCTCDecoder
+    rng = np.random.default_rng(11)
+    labels = '_AB'
+    for case in range(40):
+        t = int(rng.integers(1, 7))
+        probs = rng.dirichlet(np.ones(3) * 0.7, size=t).astype(np.float32)
+        want, p = _best_labelling_by_enumeration(probs.astype(np.float64))
+        dec = BeamCTCDecoder(labels, beam_width=64)
+        (got,), (offs,) = dec.decode(torch.from_numpy(probs[None]), None)
+        assert got[0] == ''.join(labels[c] for c in want), (case, probs)
+        assert abs(dec.last_log_probs[0] - np.log(p)) < 1e-4
+        assert len(offs[0]) == len(want) and all(int(offs[0][i]) <= int(offs[0][i + 1]) for i in range(len(want) - 1))
+        # log-probability input gives the same answer
+        dec_log = BeamCTCDecoder(labels, beam_width=64, log_input=True)
+        assert dec_log.decode(torch.from_numpy(np.log(probs)[None]), None)[0][0][0] == got[0]
+    # peaked outputs: every beam width agrees with the frame-wise collapse; `sizes` truncates
+    ids = np.array([0, 1, 1, 0, 1, 2, 2, 0, 0, 2, 1, 0])
+    probs = np.full((1, len(ids), 3), 0.005, dtype=np.float32)
+    probs[0, np.arange(len(ids)), ids] = 0.99
+    for width in (1, 4, 32):
+        dec = BeamCTCDecoder(labels, beam_width=width)
+        assert dec.decode(torch.from_numpy(probs), None)[0][0][0] == 'AABBA'
+        assert dec.decode(torch.from_numpy(probs), [6])[0][0][0] == 'AAB'
+    # the most probable labelling differs from the greedy path when probability mass is split over alignments
+    split = np.array([[[0.4, 0.6, 0.0], [0.55, 0.45, 0.0]]], dtype=np.float32)     # greedy path: A,_ -> "A" (also best)
+    assert BeamCTCDecoder(labels, beam_width=8).decode(torch.from_numpy(split), None)[0][0][0] == 'A'
+    with pytest.raises(ValueError):
+        BeamCTCDecoder(labels, beam_width=0)

@@ -198,3 +198,20 @@ def test_full_size_step_properties():
         probs = model(x.to('cuda'))
     assert tuple(probs.shape) == (10, 746, 29)
     np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_beam_decoder_agrees_with_greedy_on_confident_outputs():
+    """A width-1..16 prefix beam search returns the greedy transcript when every frame is confident."""
+    from codes.decoder import BeamCTCDecoder, GreedyDecoder
+    labels = "_'ABCDEFGHIJKLMNOPQRSTUVWXYZ "
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, 29, size=(3, 60))
+    logits = torch.full((3, 60, 29), -6.0)
+    logits.scatter_(2, torch.from_numpy(ids)[..., None], 6.0)
+    probs = torch.softmax(logits, -1).to('cuda')
+    sizes = torch.tensor([60, 41, 7], dtype=torch.int32)
+    want, _ = GreedyDecoder(labels).decode(probs, sizes)
+    for width in (1, 16):
+        got, offs = BeamCTCDecoder(labels, beam_width=width).decode(probs, sizes)
+        assert got == want
+        assert all(len(o[0]) == len(g[0]) for o, g in zip(offs, got))
