@@ -168,12 +168,16 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
                     __builtin_amdgcn_sched_barrier(0);
                     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-                    for (int i = 0; i < KBW; ++i)
+                    for (int i = 0; i < KBW; ++i) {
+                        // the step is MFMA-issue bound: a wave whose last k block lies past H (H = 800: 50 blocks
+                        // over 8 waves, six of them own 6 not 7) skips its 8 all-zero MFMAs (wave-uniform branch)
+                        if (i == KBW - 1 && wave + NWP * i >= nkb) break;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][i][e], bf[bt & 1][i][e], acc0, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[1][i][e], bf[bt & 1][i][e], acc1, 0, 0, 0);
                         }
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         red[wave][0][bt][4 * q + r][m] = acc0[r];
