@@ -159,6 +159,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON result: RCCL prints a version banner to the C-level stdout (flushed at
+    # exit, i.e. after our line), so fd 1 is pointed at stderr for the run and the result goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -282,9 +288,11 @@ def main():
     }
     if not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(plan)
-    print(json.dumps(result), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(result) + '\n').encode())
+    os.close(result_fd)
 
 
 if __name__ == '__main__':
