@@ -411,13 +411,14 @@ class DeepSpeech(nn.Module):
             grad_ready(*self._span(c[0].weight, c[4].bias))
 
     def _side_stream(self, dev):
+        """Low-priority stream for the weight-gradient GEMMs (default-priority work always gets free CUs first)."""
         st = getattr(self, '_side', None)
         if st is None or st.device != dev:
-            try:
-                lo, _hi = torch.cuda.Stream.priority_range()      # (lowest, highest priority)
-            except Exception:                                     # noqa: BLE001 - older torch: no query, default priority
-                lo = 0
-            st = self._side = torch.cuda.Stream(device=dev, priority=lo)
+            if os.environ.get('DS2_SIDE_PRIORITY', 'low') == 'low':
+                st = ops.low_priority_stream(dev)
+            else:
+                st = torch.cuda.Stream(device=dev)
+            self._side = st
         return st
 
     def _pair_view(self, gflat, p_fwd, p_rev):

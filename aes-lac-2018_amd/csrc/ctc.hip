@@ -22,17 +22,23 @@ constexpr int CTC_THREADS = 256;
 constexpr int MAX_S = 1024;  // 2*L+1 <= 1024
 #define NEG_INF_D (-(double)INFINITY)
 
+// exp / log of the bounded part on the hardware exp2 / log2 units (1 ulp): arguments are <= 0 and the sum lies in
+// [1, 3], so no range handling is needed; the library expf / logf cost ~100 more instructions per state per frame on
+// the recursion's critical path (0.75 -> 0.5 us per frame).
+__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
+__device__ __forceinline__ float log_1to3(float s) { return 0.6931471805599453f * __builtin_amdgcn_logf(s); }
+
 __device__ __forceinline__ double lse2m(double a, double b) {
     const double m = fmax(a, b);
     if (m == NEG_INF_D) return m;
-    const float s = expf((float)(a - m)) + expf((float)(b - m));
-    return m + (double)logf(s);
+    const float s = exp_neg((float)(a - m)) + exp_neg((float)(b - m));
+    return m + (double)log_1to3(s);
 }
 __device__ __forceinline__ double lse3m(double a, double b, double c) {
     const double m = fmax(fmax(a, b), c);
     if (m == NEG_INF_D) return m;
-    const float s = expf((float)(a - m)) + expf((float)(b - m)) + expf((float)(c - m));
-    return m + (double)logf(s);
+    const float s = exp_neg((float)(a - m)) + exp_neg((float)(b - m)) + exp_neg((float)(c - m));
+    return m + (double)log_1to3(s);
 }
 
 __global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ acts, int rows, int A,

@@ -176,3 +176,21 @@ extern "C" int ds2_add2(const float* a, const float* b, size_t n, float* out, vo
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }
+
+extern "C" int ds2_stream_create(int priority, void** stream_out) {
+    DS2_CHECK_ARG(stream_out);
+    int least = 0, greatest = 0;
+    DS2_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    if (priority > least) priority = least;        // numerically larger = lower priority
+    if (priority < greatest) priority = greatest;
+    hipStream_t st = nullptr;
+    DS2_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority));
+    *stream_out = (void*)st;
+    return DS2_OK;
+}
+
+extern "C" int ds2_stream_destroy(void* stream) {
+    DS2_CHECK_ARG(stream);
+    DS2_HIP(hipStreamDestroy((hipStream_t)stream));
+    return DS2_OK;
+}

@@ -53,6 +53,8 @@ SIGNATURES = {
     'ds2_sumsq': (_I, [_P, _Z, _P, _P, _P]),
     'ds2_clip_sgd_nesterov': (_I, [_P, _P, _P, _Z, _P, _F, _F, _F, _F, _I, _P]),
     'ds2_add2': (_I, [_P, _P, _Z, _P, _P]),
+    'ds2_stream_create': (_I, [_I, _P]),
+    'ds2_stream_destroy': (_I, [_P]),
     'ds2_edit_distance': (_I, [_P, _I, _P, _I]),
     'ds2_ctc_beam_search': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
 }

@@ -98,6 +98,17 @@ def spin_wait(event):
     while not event.query():
         pass
 
+
+def low_priority_stream(device):
+    """A torch stream object on a LOW-priority HIP stream (torch.cuda.Stream cannot create one: it clamps to [-1, 0])."""
+    import ctypes
+    with torch.cuda.device(device):
+        out = ctypes.c_void_p()
+        rc = lib.load().ds2_stream_create(1, ctypes.byref(out))
+        if rc != 0:
+            raise RuntimeError('ds2_stream_create failed (%d): %s' % (rc, lib.load().ds2_last_error().decode()))
+        return torch.cuda.ExternalStream(out.value, device=device)
+
 # ----------------------------------------------------------------------------- GEMM
 def gemm(a, b, trans_a=False, trans_b=False, out=None, beta=0.0, m=None, n=None, k=None, lda=None, ldb=None,
          ldc=None, split_k=1):

@@ -211,6 +211,13 @@ int ds2_clip_sgd_nesterov(float* p, const float* g, float* buf, size_t n, const 
 /* misc elementwise used by the layer glue */
 int ds2_add2(const float* a, const float* b, size_t n, float* out, void* stream);
 
+/* A HIP stream of the given priority (hipDeviceGetStreamPriorityRange: 1 = low, 0 = normal, -1 = high on
+ * gfx950).  torch.cuda.Stream clamps priorities to [-1, 0], so the LOW-priority stream the weight-gradient GEMMs run
+ * on (under the next layer's recurrence kernel, without taking CUs from the critical chain) is created here and
+ * wrapped with torch.cuda.ExternalStream.  The caller owns the stream. */
+int ds2_stream_create(int priority, void** stream_out);
+int ds2_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif
