@@ -553,6 +553,221 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// Forward recurrence on v_mfma_f32_4x4x1_16b_f32 with A-operand broadcast (CBSZ / ABID; tools/mfma4x4_bcast_probe.hip:
+// blocks are grouped 2^CBSZ at a time and every block of a group takes its A rows from the group's block ABID).
+//
+// The 16x16x4 kernel above is MFMA-issue bound (tiles r|z and n|pad, 10 of 16 batch columns: 3328 pipe cycles per
+// SIMD per step).  Here A = h (4 batch rows of one batch quad at ONE k), broadcast inside a group, and B = weights,
+// a different row group (4 units of one gate) in every block of the group:
+//   set A, CBSZ = 2: the 4 blocks of lane row g = row groups r0, r1, z0, z1 at k sub-index g      (4 k per instruction)
+//   set B, CBSZ = 1: block pairs (g, p) = row groups n0, n1 at k sub-index (g, p)                 (8 k per instruction)
+// so nothing is padded except B up to a multiple of 4, and -- unlike the plain 16-block form, where every block holds
+// a different k of the SAME output and 72 values per wave need a DPP fold -- the partial sums over k sub-indices sit
+// in different lane ROWS, which the gate threads add anyway together with the 8 waves (32 partials per output, read
+// as b128).  One dwordx4 of h per lane (k = 64 G + 16 g + 4 q + e for lane (g, q, i), batch row i) feeds the
+// 16 + 8 instructions (ABID = q resp. q & 1, e = 0..3) of a 64-wide k group: 24 MFMAs per batch quad per k group
+// instead of 2 x 16 padded 16x16x4 ones at 3.2x the cycles each.  The exchange ring has the backward kernel's layout
+// ([batch quad][G][kk = 4 g + q][rows][4 k], lane-contiguous, partial last quad compact).
+// ----------------------------------------------------------------------------------------------------------
+constexpr int FWD4_PITCH = NWP * 4 + 4;   // 32 partials (wave, lane row) + 4: 16-B aligned, rows spread over banks
+
+template <int Q>
+__device__ __forceinline__ float dpp_quad_add(float v) {   // Q = quad_perm selector: 0xB1 = xor 1, 0x4E = xor 2
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), Q, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+
+template <int NGI, int NBT>
+__global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                       float* __restrict__ hout,
+                                                                       const float* __restrict__ w_hh,
+                                                                       SyncWs* __restrict__ sync, float* __restrict__ ring,
+                                                                       int T, int B, int H, int dbg) {
+    // [batch row b][gate row 24 = (r0 r1 z0 z1 n0 n1) x 4 units][FWD4_PITCH partials]
+    extern __shared__ __attribute__((aligned(16))) float red4[];
+    __shared__ int abort_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, nslice = gridDim.x;
+    const int j0 = blockIdx.x * PJU;
+    const int g = lane >> 4, q = (lane >> 2) & 3, li = lane & 3;     // lane row, block in row, row/col in block
+    const int ncg = (B + 3) >> 2;
+    const int ng = (H + 63) >> 6;
+    const int slot_floats = ng * 64 * B;
+    if (tid == 0) abort_flag = 0;
+
+    // resident weights (B operands).  set A: block q of a lane row = row group q (gate q >> 1, units 4 (q & 1) + li);
+    // set B: block q = pair p = q >> 1, row group n(q & 1)
+    f32x4 wA[NGI][4], wB[NGI][2];
+    {
+        const int unit_a = j0 + 4 * (q & 1) + li;
+        const float* row_a = w_hh + ((size_t)dir * 3 * H + (size_t)(q >> 1) * H + (unit_a < H ? unit_a : 0)) * H;
+        const float* row_b = w_hh + ((size_t)dir * 3 * H + (size_t)2 * H + (unit_a < H ? unit_a : 0)) * H;
+#pragma unroll
+        for (int gi = 0; gi < NGI; ++gi) {
+            const int k0 = 64 * (wave + NWP * gi) + 16 * g;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int k = k0 + 4 * a;
+                wA[gi][a] = (unit_a < H && k < H) ? *reinterpret_cast<const f32x4*>(row_a + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int k = k0 + 8 * (q >> 1) + 4 * a;
+                wB[gi][a] = (unit_a < H && k < H) ? *reinterpret_cast<const f32x4*>(row_b + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    // gate role: 4 threads (part) per (batch nn [+ 16 bt], unit jj), each adds 8 of the 32 partials
+    const int part = tid & 3, jj = (tid >> 2) & 7, nn = tid >> 5;
+    const int gj = j0 + jj;
+    float hp[NBT];
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt) hp[bt] = 0.f;
+    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? s : T - 1 - s;
+        float gi_r[NBT], gi_z[NBT], gi_n[NBT], sv_a[NBT], sv_g[NBT], sv_h[NBT];
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) {              // independent of h: issue before the wait
+            const int gb = bt * 16 + nn;
+            gi_r[bt] = gi_z[bt] = gi_n[bt] = sv_a[bt] = sv_g[bt] = sv_h[bt] = 0.f;
+            if (gb < B && gj < H) {
+                const size_t gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
+                gi_r[bt] = G[gbase];
+                gi_z[bt] = G[gbase + H];
+                gi_n[bt] = G[gbase + 2 * H];
+            }
+        }
+        if (s > 0) {
+            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+                abort_flag = 1;
+            __syncthreads();
+            if (abort_flag) return;
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
+            auto chunk = [&](int c, auto nci_tag) {
+                constexpr int NCI = decltype(nci_tag)::value;
+                f32x4 bf[NCI][NGI];
+#pragma unroll
+                for (int gi = 0; gi < NGI; ++gi)
+#pragma unroll
+                    for (int ci = 0; ci < NCI; ++ci) {
+                        const int gq = wave + NWP * gi;            // wave-uniform k group
+                        const int cg = c * CGC + ci;
+                        const int rows = min(4, B - 4 * cg);
+                        const int kk = 4 * g + q;
+                        // rows past the batch and k past H load nothing (out-of-range offset -> 0)
+                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (64 * gq + 4 * kk < H && li < rows)
+                                                            ? (cg * ng * 256 + ((gq * 16 + kk) * rows + li) * 4) * 4
+                                                            : OOB_OFFSET);
+                    }
+                __builtin_amdgcn_sched_barrier(0);                 // every load out before the first MFMA
+                f32x4 accA[NCI][2], accB[NCI][2];                  // two chains per set and quad (e parity): issue rate
+#pragma unroll
+                for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) accA[ci][h2] = accB[ci][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int gi = 0; gi < NGI; ++gi)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // ABID is an immediate; consecutive instructions go to different accumulators
+#define DS2_FWD4_MFMA(ACC, W, CBSZ, ABID)                                                                          \
+    _Pragma("unroll") for (int ci = 0; ci < NCI; ++ci) ACC[ci][e & 1] =                                             \
+        __builtin_amdgcn_mfma_f32_4x4x1f32(bf[ci][gi][e], W[gi][ABID][e], ACC[ci][e & 1], CBSZ, ABID, 0);
+                        DS2_FWD4_MFMA(accA, wA, 2, 0)
+                        DS2_FWD4_MFMA(accB, wB, 1, 0)
+                        DS2_FWD4_MFMA(accA, wA, 2, 1)
+                        DS2_FWD4_MFMA(accB, wB, 1, 1)
+                        DS2_FWD4_MFMA(accA, wA, 2, 2)
+                        DS2_FWD4_MFMA(accA, wA, 2, 3)
+#undef DS2_FWD4_MFMA
+                    }
+                // D register i = batch row i of the quad; lane (g, q, li): set A -> gate row 4 q + li, k sub-index g;
+                // set B -> gate row 16 + 4 (q & 1) + li, k sub-indices (g, q >> 1): one DPP add folds the two pairs
+                const int partial = wave * 4 + g;
+#pragma unroll
+                for (int ci = 0; ci < NCI; ++ci) {
+                    const int cg = c * CGC + ci;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float* rec = red4 + (size_t)((cg * 4 + i) * 24) * FWD4_PITCH + partial;
+                        rec[(4 * q + li) * FWD4_PITCH] = accA[ci][0][i] + accA[ci][1][i];
+                        const float vb = dpp_row_shr_add<8>(accB[ci][0][i] + accB[ci][1][i]);
+                        if (q >= 2) rec[(16 + 4 * (q & 1) + li) * FWD4_PITCH] = vb;
+                    }
+                }
+            };
+            if (!(dbg & 2)) {
+                const int nfull = ncg / CGC, tail = ncg - nfull * CGC;
+#pragma unroll 1
+                for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGC>{});
+                if (tail == 1) chunk(nfull, std::integral_constant<int, 1>{});
+                else if (tail == 2) chunk(nfull, std::integral_constant<int, 2>{});
+                else if (tail == 3) chunk(nfull, std::integral_constant<int, 3>{});
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) {
+            const int gb = bt * 16 + nn;
+            float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
+            if (s > 0) {
+                if (gb < 4 * ncg) {                      // this part's 8 partials (two b128) of the three gate rows
+                    const f32x4* src = reinterpret_cast<const f32x4*>(red4 + (size_t)(gb * 24 + jj) * FWD4_PITCH) + 2 * part;
+                    constexpr int GSTR = 8 * FWD4_PITCH / 4;     // f32x4 units between gates (8 rows)
+                    const f32x4 r0 = src[0], r1 = src[1], z0 = src[GSTR], z1 = src[GSTR + 1], n0 = src[2 * GSTR],
+                                n1 = src[2 * GSTR + 1];
+                    const f32x4 rs = r0 + r1, zs = z0 + z1, ns = n0 + n1;
+                    gh_r = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+                    gh_z = (zs[0] + zs[1]) + (zs[2] + zs[3]);
+                    gh_n = (ns[0] + ns[1]) + (ns[2] + ns[3]);
+                }
+                gh_r = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_r));
+                gh_z = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_z));
+                gh_n = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_n));
+            }
+            if (gb < B && gj < H) {
+                const float r = fast_sigmoid(gi_r[bt] + gh_r);
+                const float z = fast_sigmoid(gi_z[bt] + gh_z);
+                const float n = fast_tanh(gi_n[bt] + r * gh_n);
+                const float h = (1.f - z) * n + z * hp[bt];
+                hp[bt] = h;
+                if (part == 0) {
+                    const int rows4 = min(4, B - (gb & ~3)) * 4;
+                    store_sc1(&ring[((size_t)dir * 2 + (s & 1)) * slot_floats + (size_t)(gb >> 2) * ng * 256 +
+                                    (gj >> 2) * rows4 + (gb & 3) * 4 + (gj & 3)], h);
+                }
+                sv_h[bt] = h;
+                sv_a[bt] = part == 1 ? r : (part == 2 ? z : n);
+                sv_g[bt] = gh_n;
+            }
+        }
+        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) {   // saved activations: read by later launches only, off the critical path
+            const int gb = bt * 16 + nn;
+            if (gb < B && gj < H) {
+                const size_t gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
+                if (part == 0) {
+                    hout[(((size_t)dir * T + t) * B + gb) * H + gj] = sv_h[bt];
+                    ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g[bt];
+                } else {
+                    G[gbase + (size_t)(part - 1) * H] = sv_a[bt];
+                }
+            }
+        }
+    }
+}
+
 inline int pick_kbw(int need, const int* opts, int nopts) {
     for (int i = 0; i < nopts; ++i)
         if (opts[i] >= need) return opts[i];
@@ -599,6 +814,33 @@ bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float*
         DS2_BWD_CASE(19)
     }
 #undef DS2_BWD_CASE
+    return false;
+}
+
+inline size_t fwd4_lds_bytes(int B) { return (size_t)((B + 3) / 4) * 4 * 24 * FWD4_PITCH * sizeof(float); }
+
+template <int NBT>
+bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
+                            int H, int dbg, hipStream_t st) {
+    const int opts[] = {1, 2, 3};
+    const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(H, 64), NWP), opts, 3);
+    dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
+    const size_t lds = fwd4_lds_bytes(B);
+#define DS2_FWD4_CASE(K)                                                                                         \
+    case K:                                                                                                      \
+        if (lds > 64 * 1024 &&                                                                                   \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, NBT>),              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
+            return false;                                                                                        \
+        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, NBT>), grid, block, lds, st, G, ghn, hout, w_hh, sync, ring, \
+                           T, B, H, dbg);                                                                        \
+        return true;
+    switch (ngi) {
+        DS2_FWD4_CASE(1)
+        DS2_FWD4_CASE(2)
+        DS2_FWD4_CASE(3)
+    }
+#undef DS2_FWD4_CASE
     return false;
 }
 
@@ -675,7 +917,14 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     DS2_HIP(hipMemsetAsync(sync_ws, 0, header_bytes() + ring_floats(B, H) * sizeof(float), st));
     const int dbg = dbg_flags();
     bool ok;
-    if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    // Measured (H = 800, us per step, 4x4x1 broadcast form vs 16x16x4 form): B=4 2.57 / 3.65, B=10 3.84 / 3.88,
+    // B=16 4.41 / 3.89, B=32 7.44 / 5.56 -- the 4x4x1 form's cost grows with every batch quad, the 16x16x4 form's
+    // with every tile of 16.  DS2_GRU_FWD = "4" / "16" forces one form (A/B timing).
+    const char* form = getenv("DS2_GRU_FWD");
+    const bool use4 = (form ? form[0] == '4' : B <= 12) && B <= 32 && ds2_cdiv(ds2_cdiv(H, 64), NWP) <= 3;
+    if (use4 && B <= 16) ok = launch_fwd_persistent4<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    else if (use4) ok = launch_fwd_persistent4<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    else if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_fwd_persistent<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else ok = launch_fwd_persistent<4>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     DS2_CHECK_ARG(ok);

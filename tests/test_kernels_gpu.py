@@ -264,6 +264,33 @@ def test_gru_recurrence_fwd_bwd(ops, monkeypatch, mode, t, bsz, n_in, hid):
         np.testing.assert_allclose(dw_hh_r.cpu().numpy(), gru.weight_hh_l0_reverse.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('fwd_form,bwd_form', [('4', '4'), ('16', '16'), ('4', '16'), ('16', '4')])
+@pytest.mark.parametrize('t,bsz,hid', [(7, 10, 800), (5, 27, 256), (4, 32, 800), (6, 5, 64)])
+def test_gru_persistent_mfma_forms_agree_with_step_kernels(ops, monkeypatch, fwd_form, bwd_form, t, bsz, hid):
+    """Both MFMA forms of each persistent kernel (4x4x1 and 16x16x4; the default depends on the batch size) against
+    the launch-per-step kernels on the same inputs."""
+    torch.manual_seed(t + bsz)
+    k = 1.0 / hid ** 0.5
+    w_hh = ((torch.rand(2, 3 * hid, hid) * 2 - 1) * k).to(DEV)
+    w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
+    gi = torch.randn(t, bsz, 2, 3 * hid).to(DEV)
+    d_out = torch.randn(t, bsz, hid).to(DEV)
+    res = {}
+    for mode in ('step', 'persistent'):
+        monkeypatch.setattr(ops, 'GRU_MODE', mode)
+        monkeypatch.setenv('DS2_GRU_FWD', fwd_form)
+        monkeypatch.setenv('DS2_GRU_BWD', bwd_form)
+        g = gi.clone()
+        ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
+        fwd = (g.clone(), ghn.clone(), hout.clone())
+        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
+        torch.cuda.synchronize()
+        ops.check_async_errors()
+        res[mode] = fwd + (g, ghn)
+    for a, b in zip(res['persistent'], res['step']):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=3e-5, rtol=1e-4)
+
+
 def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch):
     """T = 746 steps of the real layer shape, three times over: every hand-off must be fresh (a stale h would
     show up as an O(1) difference), and the bounded spins must never trip."""
