@@ -35,7 +35,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NSHARD = 8;  // arrival counters per direction (workgroup x -> shard x % 8), each on its own 128-B line:
                            // 100 arrivals on ONE word serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
 struct SyncWs {            // lives in caller-provided device memory, zeroed before every launch
-    unsigned int arrive[2][NSHARD][32];
+    unsigned int arrive[2][2][NSHARD][32];   // [direction][batch part (backward 16-unit form)][shard][line]
     unsigned int error;    // set to 1 on a spin timeout
 };
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
     const int gb = gbt * 16 + nn, gj = j0 + jj;
     const bool gate_ok = (gbt < NBT) && (gb < B) && (gj < H);
     float hp = 0.f;                                     // this thread's h_{t-1}, carried in a register
-    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* shards = &sync->arrive[dir][0][0][0];
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
     const int gb = gbt * 16 + nn, gj = j0 + jj;
     const bool gate_ok = (gbt < NBT) && (gb < B) && (gj < H);
     float dhz = 0.f;                                    // dh * z carried to the next (earlier) step
-    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* shards = &sync->arrive[dir][0][0][0];
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
@@ -391,33 +391,44 @@ __device__ __forceinline__ float dpp_row_shr_add(float v) {
 constexpr int CGC = 4;   // batch quads per chunk = 16 batch columns
 constexpr int RED4_PITCH = NWP * 4 + 4;   // floats per reduced value in LDS: 32 partials + 4 (bank spread, keeps 16-B alignment)
 
-template <int NGI>
+// NRG = row groups (of 4 units) per workgroup.  NRG = 2: 8 units, the whole batch.  NRG = 4: 16 units and HALF the batch
+// (blockIdx.z = batch part): the two halves are independent recurrences, the workgroup count is unchanged, every CU
+// holds twice the weights (150 KB of its 512 KB register file) but pulls only its half's d(gh) per step and waits
+// for 50 producers instead of 100.
+template <int NGI, int NRG>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        const float* __restrict__ hout,
                                                                        const float* __restrict__ d_out,
                                                                        const float* __restrict__ w_hh_t,
                                                                        SyncWs* __restrict__ sync, float* __restrict__ ring,
                                                                        int T, int B, int H, int dbg) {
-    // [value = (rg 2, cg, r 4, j 4)][RED4_PITCH: partial = wave * 4 + lane row]: a gate thread's 32 partials are
+    // [value = (rg, cg, r 4, j 4)][RED4_PITCH: partial = wave * 4 + lane row]: a gate thread's 32 partials are
     // contiguous (eight ds_read_b128 in flight; as 32 scalar reads the compiler chained read -> wait -> add, ~0.6 us
     // per step), and the pitch of 36 puts the 16 storing lanes of a fold (4 rows x 4 j) on 16 different banks
     extern __shared__ __attribute__((aligned(16))) float red4[];
     __shared__ int abort_flag;
+    constexpr int NPART = NRG / 2;                      // batch parts
+    constexpr int UNITS = 4 * NRG;                      // hidden units per workgroup
+    constexpr int CGW = NRG == 2 ? CGC : 2;             // batch quads per chunk (register budget)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, nslice = gridDim.x;
-    const int j0 = blockIdx.x * PJU;
+    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
+    const int j0 = blockIdx.x * UNITS;
     const int kk = lane >> 2, li = lane & 3;
     const int K = 3 * H;
-    const int ncg = (B + 3) >> 2;
+    const int bper = (B + NPART - 1) / NPART;           // batch rows per part (the last part may have fewer)
+    const int b0 = part * bper;
+    const int nb = min(bper, B - b0);                   // this workgroup's batch rows: b0 .. b0 + nb - 1
+    const int ncg = (nb + 3) >> 2;
     const int ng = (K + 63) >> 6;                       // 64-wide k groups
-    const int slot_floats = ng * 64 * B;                // a partial last quad keeps only its B & 3 rows
+    const int slot_floats = ng * 64 * nb;               // a partial last quad keeps only its nb & 3 rows
+    float* my_ring = ring + (size_t)(dir * NPART + part) * 2 * ((size_t)ng * 64 * bper);
     if (tid == 0) abort_flag = 0;
 
-    f32x4 wA[2][NGI];                                   // weights of unit 4 rg + li at k = 64 G + 4 kk .. +3
+    f32x4 wA[NRG][NGI];                                 // weights of unit 4 rg + li at k = 64 G + 4 kk .. +3
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {
+    for (int rg = 0; rg < NRG; ++rg) {
         const int unit = j0 + 4 * rg + li;
         const float* row = w_hh_t + ((size_t)dir * H + (unit < H ? unit : 0)) * K;
 #pragma unroll
@@ -426,11 +437,11 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             wA[rg][gi] = (unit < H && k < K) ? *reinterpret_cast<const f32x4*>(row + k) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const int jj = tid & 7, nn = (tid >> 3) & 15, gbt = tid >> 7;
-    const int gb = gbt * 16 + nn, gj = j0 + jj;
-    const bool gate_ok = (gb < B) && (gj < H);
+    const int jj = tid % UNITS, nn = tid / UNITS;       // gate role: unit jj, local batch row nn
+    const int gb = b0 + nn, gj = j0 + jj;
+    const bool gate_ok = (nn < nb) && (gj < H);
     float dhz = 0.f;
-    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* shards = &sync->arrive[dir][part][0][0];
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
@@ -440,6 +451,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
         size_t row = 0, gbase = 0;
         if (gate_ok) {
+            // saved activations of step t (written by the forward pass, an earlier launch): plain loads
             row = ((size_t)t * B + gb) * 2 + dir;
             gbase = row * 3 * H + gj;
             dh = d_out[((size_t)t * B + gb) * H + gj];
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             __syncthreads();
             if (abort_flag) return;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-                ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
+                my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
             auto chunk = [&](int c, auto nci_tag) {
                 constexpr int NCI = decltype(nci_tag)::value;
                 f32x4 bf[NCI][NGI];
@@ -464,8 +476,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 #pragma unroll
                     for (int ci = 0; ci < NCI; ++ci) {
                         const int g = wave + NWP * gi;             // wave-uniform
-                        const int cg = c * CGC + ci;
-                        const int rows = min(4, B - 4 * cg);       // batch rows this quad really has
+                        const int cg = c * CGW + ci;
+                        const int rows = min(4, nb - 4 * cg);      // batch rows this quad really has
                         // lanes of rows past the batch (and k groups past K) read nothing: out-of-range offset -> 0
                         bf[ci][gi] = LOAD_HANDOFF(rs_x, (g < ng && li < rows)
                                                             ? (cg * ng * 256 + ((g * 16 + kk) * rows + li) * 4) * 4
@@ -474,9 +486,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 // every load of the chunk goes out before the first MFMA: left alone the scheduler sinks loads in between
                 // the MFMAs and keeps only 2-5 in flight, which throttles a phase bounded by bytes in flight
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 acc[2][NCI];
+                f32x4 acc[NRG][NCI];
 #pragma unroll
-                for (int rg = 0; rg < 2; ++rg)
+                for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
                     for (int ci = 0; ci < NCI; ++ci) acc[rg][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -484,17 +496,17 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int ci = 0; ci < NCI; ++ci) {
-                            acc[0][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[0][gi][e], bf[ci][gi][e], acc[0][ci], 0, 0, 0);
-                            acc[1][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[1][gi][e], bf[ci][gi][e], acc[1][ci], 0, 0, 0);
-                        }
+                        for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                            for (int rg = 0; rg < NRG; ++rg)
+                                acc[rg][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[rg][gi][e], bf[ci][gi][e], acc[rg][ci], 0, 0, 0);
                 // fold the 16 per-block partials: two DPP adds leave each 16-lane row's sum in its lanes 12..15
                 float* rec = red4 + (lane & 3) * RED4_PITCH + wave * 4 + (lane >> 4);
 #pragma unroll
-                for (int rg = 0; rg < 2; ++rg)
+                for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
                     for (int ci = 0; ci < NCI; ++ci) {
-                        const int cg = c * CGC + ci;
+                        const int cg = c * CGW + ci;
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             float v = acc[rg][ci][rr];
@@ -505,18 +517,20 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                     }
             };
             if (!(dbg & 2)) {
-                const int nfull = ncg / CGC, tail = ncg - nfull * CGC;
+                const int nfull = ncg / CGW, tail = ncg - nfull * CGW;
 #pragma unroll 1
-                for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGC>{});
+                for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGW>{});
                 if (tail == 1) chunk(nfull, std::integral_constant<int, 1>{});
-                else if (tail == 2) chunk(nfull, std::integral_constant<int, 2>{});
-                else if (tail == 3) chunk(nfull, std::integral_constant<int, 3>{});
+                if constexpr (CGW > 2) {
+                    if (tail == 2) chunk(nfull, std::integral_constant<int, 2>{});
+                    else if (tail == 3) chunk(nfull, std::integral_constant<int, 3>{});
+                }
             }
         }
         __syncthreads();
         if (gate_ok) {
             if (s > 0) {
-                const int rg = jj >> 2, rr = jj & 3, cg = gb >> 2, bj = gb & 3;
+                const int rg = jj >> 2, rr = jj & 3, cg = nn >> 2, bj = nn & 3;
                 const f32x4* src = reinterpret_cast<const f32x4*>(red4 + (((rg * ncg + cg) * 4 + rr) * 4 + bj) * RED4_PITCH);
                 f32x4 p[NWP];
 #pragma unroll
@@ -529,8 +543,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             const float dr_pre = dn_pre * gn * r * (1.f - r);
             dhz = dh * z;
             {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
-                const int rows4 = min(4, B - (gb & ~3)) * 4;   // floats per (k quad) of this batch quad
-                float* slot = ring + ((size_t)dir * 2 + (s & 1)) * slot_floats + (size_t)(gb >> 2) * ng * 256 + (gb & 3) * 4;
+                const int rows4 = min(4, nb - (nn & ~3)) * 4;   // floats per (k quad) of this batch quad
+                float* slot = my_ring + (size_t)(s & 1) * slot_floats + (size_t)(nn >> 2) * ng * 256 + (nn & 3) * 4;
                 const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
                 store_sc1(&slot[(k0 >> 2) * rows4 + (k0 & 3)], dr_pre);
                 store_sc1(&slot[(k1 >> 2) * rows4 + (k1 & 3)], dz_pre);
@@ -626,7 +640,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     float hp[NBT];
 #pragma unroll
     for (int bt = 0; bt < NBT; ++bt) hp[bt] = 0.f;
-    unsigned int* shards = &sync->arrive[dir][0][0];
+    unsigned int* shards = &sync->arrive[dir][0][0][0];
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
@@ -844,21 +858,23 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
     return false;
 }
 
+template <int NRG>
 bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                             SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3, 5};
     const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
-    dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
-    const int ncg = (B + 3) / 4;
-    const size_t lds = (size_t)2 * ncg * 16 * RED4_PITCH * sizeof(float);
+    constexpr int NPART = NRG / 2;
+    dim3 grid(ds2_cdiv(H, 4 * NRG), 2, NPART), block(NWP * 64);
+    const int ncg = (ds2_cdiv(B, NPART) + 3) / 4;
+    const size_t lds = (size_t)NRG * ncg * 16 * RED4_PITCH * sizeof(float);
 #define DS2_BWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K>),                   \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K, NRG>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
-        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t, sync, \
-                           ring, T, B, H, dbg);                                                                  \
+        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K, NRG>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t,    \
+                           sync, ring, T, B, H, dbg);                                                            \
         return true;
     switch (ngi) {
         DS2_BWD4_CASE(1)
@@ -892,7 +908,7 @@ inline int dbg_flags() {
 // exchange ring: [dir 2][slot 2][batch tiles][k blocks of 16][16][16] floats, sized for the backward pass (K = 3H)
 inline size_t ring_floats(int B, int H) {
     const size_t a = (size_t)ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256;          // 16x16x4 forms
-    const size_t b = (size_t)B * (size_t)ds2_cdiv(3 * H, 64) * 64;                  // 4x4x1 backward form
+    const size_t b = (size_t)2 * ds2_cdiv(B, 2) * (size_t)ds2_cdiv(3 * H, 64) * 64;   // 4x4x1 forms (two batch parts)
     return (size_t)2 * 2 * (a > b ? a : b);
 }
 
@@ -948,8 +964,16 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     bool ok;
     const char* form = getenv("DS2_GRU_BWD");   // "16" selects the 16x16x4 MFMA form (A/B timing); default: 4x4x1
     const bool use4 = form ? form[0] == '4' : true;
-    if (use4 && ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5)
-        ok = launch_bwd_persistent4(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    // 16 units x half the batch per workgroup where that removes a batch quad per workgroup without adding MFMAs
+    // (measured, H = 800, us per step, whole batch / two halves: B=8 3.32 / 2.98, B=10 3.90 / 4.04, B=16 4.77 / 4.09,
+    // B=32 7.48 / 6.51, B=64 12.84 / 11.38); DS2_GRU_BWD_SPLIT = 1 / 2 forces a form (A/B timing)
+    const char* split = getenv("DS2_GRU_BWD_SPLIT");
+    const int q_whole = (B + 3) / 4, q_half = (ds2_cdiv(B, 2) + 3) / 4;
+    const bool two_parts = split ? split[0] == '2' : (B >= 2 && 2 * q_half <= q_whole);
+    if (use4 && ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5 && two_parts && B >= 2)
+        ok = launch_bwd_persistent4<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else if (use4 && ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5)
+        ok = launch_bwd_persistent4<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
