@@ -35,7 +35,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int NSHARD = 8;  // arrival counters per direction (workgroup x -> shard x % 8), each on its own 128-B line:
                            // 100 arrivals on ONE word serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
 struct SyncWs {            // lives in caller-provided device memory, zeroed before every launch
-    unsigned int arrive[2][2][NSHARD][32];   // [direction][batch part (backward 16-unit form)][shard][line]
+    unsigned int arrive[2][3][NSHARD][32];   // [direction][batch part (backward batch-split forms)][shard][line]
     unsigned int error;    // set to 1 on a spin timeout
 };
 
@@ -391,10 +391,12 @@ __device__ __forceinline__ float dpp_row_shr_add(float v) {
 constexpr int CGC = 4;   // batch quads per chunk = 16 batch columns
 constexpr int RED4_PITCH = NWP * 4 + 4;   // floats per reduced value in LDS: 32 partials + 4 (bank spread, keeps 16-B alignment)
 
-// NRG = row groups (of 4 units) per workgroup.  NRG = 2: 8 units, the whole batch.  NRG = 4: 16 units and HALF the batch
-// (blockIdx.z = batch part): the two halves are independent recurrences, the workgroup count is unchanged, every CU
-// holds twice the weights (150 KB of its 512 KB register file) but pulls only its half's d(gh) per step and waits
-// for 50 producers instead of 100.
+// NRG = row groups (of 4 units) per workgroup.  NRG = 2: 8 units, the whole batch.  NRG = 4 / 6: 16 / 24 units and a
+// HALF / THIRD of the batch (blockIdx.z = batch part): the parts are independent recurrences, the workgroup count stays
+// ~200, every CU holds 2x / 3x the weights (150 / 230 KB of its 512 KB register file) but pulls only its part's d(gh)
+// per step and waits for 50 / 34 producers instead of 100.  The launcher picks the form with a cost model fitted to
+// measurements: a step costs ~0.40 us per (batch quad x 8 units) of MFMA + fold work and ~0.34 us per 4 batch rows
+// of hand-off loads per workgroup.
 template <int NGI, int NRG>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        const float* __restrict__ hout,
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     __shared__ int abort_flag;
     constexpr int NPART = NRG / 2;                      // batch parts
     constexpr int UNITS = 4 * NRG;                      // hidden units per workgroup
-    constexpr int CGW = NRG == 2 ? CGC : 2;             // batch quads per chunk (register budget)
+    constexpr int CGW = NRG == 2 ? CGC : (NRG == 4 ? 2 : 1);   // batch quads per chunk (register budget)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -424,6 +426,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     const int ng = (K + 63) >> 6;                       // 64-wide k groups
     const int slot_floats = ng * 64 * nb;               // a partial last quad keeps only its nb & 3 rows
     float* my_ring = ring + (size_t)(dir * NPART + part) * 2 * ((size_t)ng * 64 * bper);
+    if (nb <= 0) return;                                // an empty batch part: nobody waits for it
     if (tid == 0) abort_flag = 0;
 
     f32x4 wA[NRG][NGI];                                 // weights of unit 4 rg + li at k = 64 G + 4 kk .. +3
@@ -520,7 +523,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 const int nfull = ncg / CGW, tail = ncg - nfull * CGW;
 #pragma unroll 1
                 for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGW>{});
-                if (tail == 1) chunk(nfull, std::integral_constant<int, 1>{});
+                if constexpr (CGW > 1) {
+                    if (tail == 1) chunk(nfull, std::integral_constant<int, 1>{});
+                }
                 if constexpr (CGW > 2) {
                     if (tail == 2) chunk(nfull, std::integral_constant<int, 2>{});
                     else if (tail == 3) chunk(nfull, std::integral_constant<int, 3>{});
@@ -908,7 +913,8 @@ inline int dbg_flags() {
 // exchange ring: [dir 2][slot 2][batch tiles][k blocks of 16][16][16] floats, sized for the backward pass (K = 3H)
 inline size_t ring_floats(int B, int H) {
     const size_t a = (size_t)ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256;          // 16x16x4 forms
-    const size_t b = (size_t)2 * ds2_cdiv(B, 2) * (size_t)ds2_cdiv(3 * H, 64) * 64;   // 4x4x1 forms (two batch parts)
+    const size_t b2 = (size_t)2 * ds2_cdiv(B, 2), b3 = (size_t)3 * ds2_cdiv(B, 3);
+    const size_t b = (b2 > b3 ? b2 : b3) * (size_t)ds2_cdiv(3 * H, 64) * 64;          // 4x4x1 forms (1-3 batch parts)
     return (size_t)2 * 2 * (a > b ? a : b);
 }
 
@@ -964,15 +970,30 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     bool ok;
     const char* form = getenv("DS2_GRU_BWD");   // "16" selects the 16x16x4 MFMA form (A/B timing); default: 4x4x1
     const bool use4 = form ? form[0] == '4' : true;
-    // 16 units x half the batch per workgroup where that removes a batch quad per workgroup without adding MFMAs
-    // (measured, H = 800, us per step, whole batch / two halves: B=8 3.32 / 2.98, B=10 3.90 / 4.04, B=16 4.77 / 4.09,
-    // B=32 7.48 / 6.51, B=64 12.84 / 11.38); DS2_GRU_BWD_SPLIT = 1 / 2 forces a form (A/B timing)
-    const char* split = getenv("DS2_GRU_BWD_SPLIT");
-    const int q_whole = (B + 3) / 4, q_half = (ds2_cdiv(B, 2) + 3) / 4;
-    const bool two_parts = split ? split[0] == '2' : (B >= 2 && 2 * q_half <= q_whole);
-    if (use4 && ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5 && two_parts && B >= 2)
+    // Batch parts (1, 2 or 3: 8, 16 or 24 units per workgroup) by the fitted cost model; measured, H = 800, us per step,
+    // whole batch / two halves: B=8 3.32 / 2.98, B=10 3.90 / 4.04, B=16 4.77 / 4.09, B=32 7.48 / 6.51, B=64 12.84 / 11.38.
+    // DS2_GRU_BWD_SPLIT = 1 / 2 / 3 forces a form (A/B timing).
+    int parts = 1;
+    {
+        double best = 1e30;
+        for (int p = 1; p <= 3; ++p) {
+            if (p > B || 2 * ds2_cdiv(H, 8 * p) * p > 240 || ds2_cdiv(B, p) * 8 * p > NWP * 64) continue;
+            const int bper = ds2_cdiv(B, p), quads = (bper + 3) / 4;
+            const double cost = 0.40 * quads * p + 0.34 * bper / 4.0 + (p == 3 && quads > 2 ? 0.3 : 0.0);
+            if (cost < best - 1e-9) {
+                best = cost;
+                parts = p;
+            }
+        }
+        const char* split = getenv("DS2_GRU_BWD_SPLIT");
+        if (split && split[0] >= '1' && split[0] <= '3' && (split[0] - '0') <= B) parts = split[0] - '0';
+    }
+    const bool ngi_ok = ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5;
+    if (use4 && ngi_ok && parts == 3)
+        ok = launch_bwd_persistent4<6>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else if (use4 && ngi_ok && parts == 2)
         ok = launch_bwd_persistent4<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-    else if (use4 && ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5)
+    else if (use4 && ngi_ok)
         ok = launch_bwd_persistent4<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
