@@ -597,55 +597,73 @@ __device__ __forceinline__ float dpp_quad_add(float v) {   // Q = quad_perm sele
     return v + __int_as_float(t);
 }
 
-template <int NGI, int NBT>
+// P = batch parts (blockIdx.z), as in the backward kernel: a workgroup owns 8 P units and 1/P of the batch.  Its 6 P row
+// groups (gate-major: rgi = gate * 2 P + unit group) are dealt, four at a time, to "A sets" (CBSZ = 2) and a last pair to
+// a "B set" (CBSZ = 1) when 6 P is not a multiple of 4:  P = 1: (r0 r1 z0 z1) + (n0 n1);  P = 2: (r0-3) (z0-3) (n0-3);
+// P = 3: (r0-3) (r4 r5 z0 z1) (z2-5) (n0-3) + (n4 n5).
+template <int NGI, int P, int NBT>
 __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        float* __restrict__ hout,
                                                                        const float* __restrict__ w_hh,
                                                                        SyncWs* __restrict__ sync, float* __restrict__ ring,
                                                                        int T, int B, int H, int dbg) {
-    // [batch row b][gate row 24 = (r0 r1 z0 z1 n0 n1) x 4 units][FWD4_PITCH partials]
+    // [local batch row][gate row = gate * UNITS + unit][FWD4_PITCH partials]
     extern __shared__ __attribute__((aligned(16))) float red4[];
     __shared__ int abort_flag;
+    constexpr int UG = 2 * P, UNITS = 8 * P, NRGI = 6 * P, ROWS = 3 * UNITS;
+    constexpr int NA = NRGI / 4, NBS = (NRGI % 4) / 2;
+    constexpr int CGW = P == 1 ? CGC : (P == 2 ? 2 : 1);   // batch quads per chunk (register budget)
+    constexpr int RPP = (NWP * 64) / (4 * UNITS);          // batch rows the gate role covers per pass (16, 8, 5)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, nslice = gridDim.x;
-    const int j0 = blockIdx.x * PJU;
+    const int dir = blockIdx.y, bpart = blockIdx.z, nslice = gridDim.x;
+    const int j0 = blockIdx.x * UNITS;
     const int g = lane >> 4, q = (lane >> 2) & 3, li = lane & 3;     // lane row, block in row, row/col in block
-    const int ncg = (B + 3) >> 2;
+    const int bper = (B + P - 1) / P;
+    const int b0 = bpart * bper;
+    const int nb = min(bper, B - b0);
+    if (nb <= 0) return;
+    const int ncg = (nb + 3) >> 2;
     const int ng = (H + 63) >> 6;
-    const int slot_floats = ng * 64 * B;
+    const int slot_floats = ng * 64 * nb;
+    float* my_ring = ring + (size_t)(dir * P + bpart) * 2 * ((size_t)ng * 64 * bper);
     if (tid == 0) abort_flag = 0;
 
-    // resident weights (B operands).  set A: block q of a lane row = row group q (gate q >> 1, units 4 (q & 1) + li);
-    // set B: block q = pair p = q >> 1, row group n(q & 1)
-    f32x4 wA[NGI][4], wB[NGI][2];
-    {
-        const int unit_a = j0 + 4 * (q & 1) + li;
-        const float* row_a = w_hh + ((size_t)dir * 3 * H + (size_t)(q >> 1) * H + (unit_a < H ? unit_a : 0)) * H;
-        const float* row_b = w_hh + ((size_t)dir * 3 * H + (size_t)2 * H + (unit_a < H ? unit_a : 0)) * H;
+    // resident weights (B operands): set A a, block q = row group 4 a + q; set B: block q = pair q >> 1, row group 4 NA + (q & 1)
+    f32x4 wA[NA][NGI][4], wB[NBS > 0 ? NBS : 1][NGI][2];
+    auto weight_row = [&](int rgi) {
+        const int gate = rgi / UG, unit = j0 + 4 * (rgi % UG) + li;
+        return unit < H ? w_hh + ((size_t)dir * 3 * H + (size_t)gate * H + unit) * H : nullptr;
+    };
 #pragma unroll
-        for (int gi = 0; gi < NGI; ++gi) {
-            const int k0 = 64 * (wave + NWP * gi) + 16 * g;
+    for (int gi = 0; gi < NGI; ++gi) {
+        const int k0 = 64 * (wave + NWP * gi) + 16 * g;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int k = k0 + 4 * a;
-                wA[gi][a] = (unit_a < H && k < H) ? *reinterpret_cast<const f32x4*>(row_a + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < NA; ++a) {
+            const float* row = weight_row(4 * a + q);
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                const int k = k0 + 4 * ab;
+                wA[a][gi][ab] = (row && k < H) ? *reinterpret_cast<const f32x4*>(row + k) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+        }
+        if constexpr (NBS > 0) {
+            const float* row = weight_row(4 * NA + (q & 1));
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int k = k0 + 8 * (q >> 1) + 4 * a;
-                wB[gi][a] = (unit_a < H && k < H) ? *reinterpret_cast<const f32x4*>(row_b + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ab = 0; ab < 2; ++ab) {
+                const int k = k0 + 8 * (q >> 1) + 4 * ab;
+                wB[0][gi][ab] = (row && k < H) ? *reinterpret_cast<const f32x4*>(row + k) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     }
-    // gate role: 4 threads (part) per (batch nn [+ 16 bt], unit jj), each adds 8 of the 32 partials
-    const int part = tid & 3, jj = (tid >> 2) & 7, nn = tid >> 5;
+    // gate role: 4 threads (gpart) per (local batch row nn [+ RPP bt], unit jj), each adds 8 of the 32 partials
+    const int gpart = tid & 3, jj = (tid >> 2) % UNITS, nn = (tid >> 2) / UNITS;
     const int gj = j0 + jj;
     float hp[NBT];
 #pragma unroll
     for (int bt = 0; bt < NBT; ++bt) hp[bt] = 0.f;
-    unsigned int* shards = &sync->arrive[dir][0][0][0];
+    unsigned int* shards = &sync->arrive[dir][bpart][0][0];
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
@@ -654,10 +672,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         float gi_r[NBT], gi_z[NBT], gi_n[NBT], sv_a[NBT], sv_g[NBT], sv_h[NBT];
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {              // independent of h: issue before the wait
-            const int gb = bt * 16 + nn;
+            const int lb = bt * RPP + nn;
             gi_r[bt] = gi_z[bt] = gi_n[bt] = sv_a[bt] = sv_g[bt] = sv_h[bt] = 0.f;
-            if (gb < B && gj < H) {
-                const size_t gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
+            if (nn < RPP && lb < nb && gj < H) {
+                const size_t gbase = (((size_t)t * B + b0 + lb) * 2 + dir) * 3 * H + gj;
                 gi_r[bt] = G[gbase];
                 gi_z[bt] = G[gbase + H];
                 gi_n[bt] = G[gbase + 2 * H];
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
             __syncthreads();
             if (abort_flag) return;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-                ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
+                my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
             auto chunk = [&](int c, auto nci_tag) {
                 constexpr int NCI = decltype(nci_tag)::value;
                 f32x4 bf[NCI][NGI];
@@ -678,8 +696,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
 #pragma unroll
                     for (int ci = 0; ci < NCI; ++ci) {
                         const int gq = wave + NWP * gi;            // wave-uniform k group
-                        const int cg = c * CGC + ci;
-                        const int rows = min(4, B - 4 * cg);
+                        const int cg = c * CGW + ci;
+                        const int rows = min(4, nb - 4 * cg);
                         const int kk = 4 * g + q;
                         // rows past the batch and k past H load nothing (out-of-range offset -> 0)
                         bf[ci][gi] = LOAD_HANDOFF(rs_x, (64 * gq + 4 * kk < H && li < rows)
@@ -687,60 +705,81 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                                                             : OOB_OFFSET);
                     }
                 __builtin_amdgcn_sched_barrier(0);                 // every load out before the first MFMA
-                f32x4 accA[NCI][2], accB[NCI][2];                  // two chains per set and quad (e parity): issue rate
+                // two chains per set and quad (e parity): a wave needs ~12 independent chains to issue every 10 cycles
+                f32x4 accA[NA][NCI][2], accB[NBS > 0 ? NBS : 1][NCI][2];
 #pragma unroll
                 for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) accA[ci][h2] = accB[ci][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) accA[a][ci][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        accB[0][ci][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
 #pragma unroll
                 for (int gi = 0; gi < NGI; ++gi)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         // ABID is an immediate; consecutive instructions go to different accumulators
-#define DS2_FWD4_MFMA(ACC, W, CBSZ, ABID)                                                                          \
-    _Pragma("unroll") for (int ci = 0; ci < NCI; ++ci) ACC[ci][e & 1] =                                             \
-        __builtin_amdgcn_mfma_f32_4x4x1f32(bf[ci][gi][e], W[gi][ABID][e], ACC[ci][e & 1], CBSZ, ABID, 0);
-                        DS2_FWD4_MFMA(accA, wA, 2, 0)
-                        DS2_FWD4_MFMA(accB, wB, 1, 0)
-                        DS2_FWD4_MFMA(accA, wA, 2, 1)
-                        DS2_FWD4_MFMA(accB, wB, 1, 1)
-                        DS2_FWD4_MFMA(accA, wA, 2, 2)
-                        DS2_FWD4_MFMA(accA, wA, 2, 3)
-#undef DS2_FWD4_MFMA
+#define DS2_FWD4_MFMA_A(ABID)                                                                                      \
+    _Pragma("unroll") for (int a = 0; a < NA; ++a) _Pragma("unroll") for (int ci = 0; ci < NCI; ++ci)              \
+        accA[a][ci][e & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[ci][gi][e], wA[a][gi][ABID][e], accA[a][ci][e & 1], 2, ABID, 0);
+#define DS2_FWD4_MFMA_B(ABID)                                                                                      \
+    if constexpr (NBS > 0) {                                                                                       \
+        _Pragma("unroll") for (int ci = 0; ci < NCI; ++ci) accB[0][ci][e & 1] =                                    \
+            __builtin_amdgcn_mfma_f32_4x4x1f32(bf[ci][gi][e], wB[0][gi][ABID][e], accB[0][ci][e & 1], 1, ABID, 0); \
+    }
+                        DS2_FWD4_MFMA_A(0)
+                        DS2_FWD4_MFMA_B(0)
+                        DS2_FWD4_MFMA_A(1)
+                        DS2_FWD4_MFMA_B(1)
+                        DS2_FWD4_MFMA_A(2)
+                        DS2_FWD4_MFMA_A(3)
+#undef DS2_FWD4_MFMA_A
+#undef DS2_FWD4_MFMA_B
                     }
-                // D register i = batch row i of the quad; lane (g, q, li): set A -> gate row 4 q + li, k sub-index g;
-                // set B -> gate row 16 + 4 (q & 1) + li, k sub-indices (g, q >> 1): one DPP add folds the two pairs
+                // D register i = batch row i of the quad; lane (g, q, li): set A a -> gate row 4 (4 a + q) + li, k
+                // sub-index g; set B -> gate row 4 (4 NA + (q & 1)) + li, k sub-indices (g, q >> 1): one DPP add folds
+                // the two pairs
                 const int partial = wave * 4 + g;
 #pragma unroll
                 for (int ci = 0; ci < NCI; ++ci) {
-                    const int cg = c * CGC + ci;
+                    const int cg = c * CGW + ci;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float* rec = red4 + (size_t)((cg * 4 + i) * 24) * FWD4_PITCH + partial;
-                        rec[(4 * q + li) * FWD4_PITCH] = accA[ci][0][i] + accA[ci][1][i];
-                        const float vb = dpp_row_shr_add<8>(accB[ci][0][i] + accB[ci][1][i]);
-                        if (q >= 2) rec[(16 + 4 * (q & 1) + li) * FWD4_PITCH] = vb;
+                        float* rec = red4 + (size_t)((cg * 4 + i) * ROWS) * FWD4_PITCH + partial;
+#pragma unroll
+                        for (int a = 0; a < NA; ++a)
+                            rec[(4 * (4 * a + q) + li) * FWD4_PITCH] = accA[a][ci][0][i] + accA[a][ci][1][i];
+                        if constexpr (NBS > 0) {
+                            const float vb = dpp_row_shr_add<8>(accB[0][ci][0][i] + accB[0][ci][1][i]);
+                            if (q >= 2) rec[(4 * (4 * NA + (q & 1)) + li) * FWD4_PITCH] = vb;
+                        }
                     }
                 }
             };
             if (!(dbg & 2)) {
-                const int nfull = ncg / CGC, tail = ncg - nfull * CGC;
+                const int nfull = ncg / CGW, tail = ncg - nfull * CGW;
 #pragma unroll 1
-                for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGC>{});
-                if (tail == 1) chunk(nfull, std::integral_constant<int, 1>{});
-                else if (tail == 2) chunk(nfull, std::integral_constant<int, 2>{});
-                else if (tail == 3) chunk(nfull, std::integral_constant<int, 3>{});
+                for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGW>{});
+                if constexpr (CGW > 1) {
+                    if (tail == 1) chunk(nfull, std::integral_constant<int, 1>{});
+                }
+                if constexpr (CGW > 2) {
+                    if (tail == 2) chunk(nfull, std::integral_constant<int, 2>{});
+                    else if (tail == 3) chunk(nfull, std::integral_constant<int, 3>{});
+                }
             }
         }
         __syncthreads();
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {
-            const int gb = bt * 16 + nn;
+            const int lb = bt * RPP + nn;
+            const bool mine = nn < RPP && lb < nb && gj < H;
             float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
             if (s > 0) {
-                if (gb < 4 * ncg) {                      // this part's 8 partials (two b128) of the three gate rows
-                    const f32x4* src = reinterpret_cast<const f32x4*>(red4 + (size_t)(gb * 24 + jj) * FWD4_PITCH) + 2 * part;
-                    constexpr int GSTR = 8 * FWD4_PITCH / 4;     // f32x4 units between gates (8 rows)
+                if (nn < RPP && lb < 4 * ncg) {          // this gpart's 8 partials (two b128) of the three gate rows
+                    const f32x4* src = reinterpret_cast<const f32x4*>(red4 + (size_t)(lb * ROWS + jj) * FWD4_PITCH) + 2 * gpart;
+                    constexpr int GSTR = UNITS * FWD4_PITCH / 4;     // f32x4 units between gates
                     const f32x4 r0 = src[0], r1 = src[1], z0 = src[GSTR], z1 = src[GSTR + 1], n0 = src[2 * GSTR],
                                 n1 = src[2 * GSTR + 1];
                     const f32x4 rs = r0 + r1, zs = z0 + z1, ns = n0 + n1;
@@ -752,19 +791,19 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 gh_z = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_z));
                 gh_n = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_n));
             }
-            if (gb < B && gj < H) {
+            if (mine) {
                 const float r = fast_sigmoid(gi_r[bt] + gh_r);
                 const float z = fast_sigmoid(gi_z[bt] + gh_z);
                 const float n = fast_tanh(gi_n[bt] + r * gh_n);
                 const float h = (1.f - z) * n + z * hp[bt];
                 hp[bt] = h;
-                if (part == 0) {
-                    const int rows4 = min(4, B - (gb & ~3)) * 4;
-                    store_sc1(&ring[((size_t)dir * 2 + (s & 1)) * slot_floats + (size_t)(gb >> 2) * ng * 256 +
-                                    (gj >> 2) * rows4 + (gb & 3) * 4 + (gj & 3)], h);
+                if (gpart == 0) {
+                    const int rows4 = min(4, nb - (lb & ~3)) * 4;
+                    store_sc1(&my_ring[(size_t)(s & 1) * slot_floats + (size_t)(lb >> 2) * ng * 256 + (gj >> 2) * rows4 +
+                                       (lb & 3) * 4 + (gj & 3)], h);
                 }
                 sv_h[bt] = h;
-                sv_a[bt] = part == 1 ? r : (part == 2 ? z : n);
+                sv_a[bt] = gpart == 1 ? r : (gpart == 2 ? z : n);
                 sv_g[bt] = gh_n;
             }
         }
@@ -773,14 +812,15 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {   // saved activations: read by later launches only, off the critical path
-            const int gb = bt * 16 + nn;
-            if (gb < B && gj < H) {
+            const int lb = bt * RPP + nn;
+            if (nn < RPP && lb < nb && gj < H) {
+                const int gb = b0 + lb;
                 const size_t gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
-                if (part == 0) {
+                if (gpart == 0) {
                     hout[(((size_t)dir * T + t) * B + gb) * H + gj] = sv_h[bt];
                     ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g[bt];
                 } else {
-                    G[gbase + (size_t)(part - 1) * H] = sv_a[bt];
+                    G[gbase + (size_t)(gpart - 1) * H] = sv_a[bt];
                 }
             }
         }
@@ -836,23 +876,22 @@ bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float*
     return false;
 }
 
-inline size_t fwd4_lds_bytes(int B) { return (size_t)((B + 3) / 4) * 4 * 24 * FWD4_PITCH * sizeof(float); }
-
-template <int NBT>
+template <int P, int NBT>
 bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
                             int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3};
     const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(H, 64), NWP), opts, 3);
-    dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
-    const size_t lds = fwd4_lds_bytes(B);
+    dim3 grid(ds2_cdiv(H, 8 * P), 2, P), block(NWP * 64);
+    const int ncg = (ds2_cdiv(B, P) + 3) / 4;
+    const size_t lds = (size_t)ncg * 4 * 24 * P * FWD4_PITCH * sizeof(float);
 #define DS2_FWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, NBT>),              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, P, NBT>),           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
-        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, NBT>), grid, block, lds, st, G, ghn, hout, w_hh, sync, ring, \
-                           T, B, H, dbg);                                                                        \
+        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, P, NBT>), grid, block, lds, st, G, ghn, hout, w_hh, sync,    \
+                           ring, T, B, H, dbg);                                                                  \
         return true;
     switch (ngi) {
         DS2_FWD4_CASE(1)
@@ -939,13 +978,34 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     DS2_HIP(hipMemsetAsync(sync_ws, 0, header_bytes() + ring_floats(B, H) * sizeof(float), st));
     const int dbg = dbg_flags();
     bool ok;
-    // Measured (H = 800, us per step, 4x4x1 broadcast form vs 16x16x4 form): B=4 2.57 / 3.65, B=10 3.84 / 3.88,
-    // B=16 4.41 / 3.89, B=32 7.44 / 5.56 -- the 4x4x1 form's cost grows with every batch quad, the 16x16x4 form's
-    // with every tile of 16.  DS2_GRU_FWD = "4" / "16" forces one form (A/B timing).
+    // Form by batch size.  Measured (H = 800, us per step, 4x4x1 broadcast form with the whole batch per workgroup vs
+    // 16x16x4 form): B=4 2.57 / 3.65, B=10 3.84 / 3.88, B=16 4.41 / 3.89, B=32 7.44 / 5.56 -- the 4x4x1 form's cost
+    // grows with every batch quad (and, with batch parts, with quads x parts for the MFMAs but only quads for the
+    // loads), the 16x16x4 form's with every tile of 16.  DS2_GRU_FWD = "4" / "16" forces a form, DS2_GRU_FWD_SPLIT =
+    // 1 / 2 / 3 the number of batch parts (A/B timing).
     const char* form = getenv("DS2_GRU_FWD");
-    const bool use4 = (form ? form[0] == '4' : B <= 12) && B <= 32 && ds2_cdiv(ds2_cdiv(H, 64), NWP) <= 3;
-    if (use4 && B <= 16) ok = launch_fwd_persistent4<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
-    else if (use4) ok = launch_fwd_persistent4<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    const bool ngi_ok = ds2_cdiv(ds2_cdiv(H, 64), NWP) <= 3;
+    int parts = B <= 4 ? 1 : (B <= 8 ? 2 : 3);
+    {
+        const char* split = getenv("DS2_GRU_FWD_SPLIT");
+        if (split && split[0] >= '1' && split[0] <= '3') parts = split[0] - '0';
+        if (parts > B) parts = B;
+        // gate-role capacity: two passes of 512 / (4 * 8 parts) batch rows per workgroup; all workgroups co-resident
+        while (parts < 3 && ds2_cdiv(B, parts) > 2 * (NWP * 64 / (32 * parts))) ++parts;
+        if (2 * ds2_cdiv(H, 8 * parts) * parts > 240) parts = 1;
+    }
+    const int bper = ds2_cdiv(B, parts), rpp = NWP * 64 / (32 * parts);
+    const bool fits4 = ngi_ok && bper <= 2 * rpp && (size_t)((bper + 3) / 4) * 4 * 24 * parts * FWD4_PITCH * 4 <= 140 * 1024;
+    const bool use4 = (form ? form[0] == '4' : B <= 12) && fits4;
+    if (use4) {
+        const bool two = bper > rpp;
+        if (parts == 1) ok = two ? launch_fwd_persistent4<1, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
+                                 : launch_fwd_persistent4<1, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+        else if (parts == 2) ok = two ? launch_fwd_persistent4<2, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
+                                      : launch_fwd_persistent4<2, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+        else ok = two ? launch_fwd_persistent4<3, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
+                      : launch_fwd_persistent4<3, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    }
     else if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_fwd_persistent<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else ok = launch_fwd_persistent<4>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
