@@ -386,13 +386,16 @@ class DeepSpeech(nn.Module):
             if side is not None:
                 keepalive.append(dict(rec))        # the side stream still reads these; freed after the join below
             rec.clear()
-        if side is not None:
-            main.wait_stream(side)                  # every later consumer of the gradients sits behind this join
-        keepalive.clear()
+        # The side stream may still be working through weight-gradient GEMMs (it only gets the CUs the recurrence
+        # kernels leave free): the conv block's backward below runs beside that backlog, and the ONE join with the
+        # side stream is at the end of this function.  `keepalive` keeps the tensors it reads allocated until then.
         c = self.conv
         if sv.get('conv_frozen', False):             # frozen conv block: nothing upstream needs a gradient
             lo, hi = self._span(c[0].weight, c[4].bias)
             gflat[lo:hi].zero_()
+            if side is not None:
+                main.wait_stream(side)
+            keepalive.clear()
             if grad_ready is not None:
                 grad_ready(lo, hi)
             return
@@ -406,7 +409,8 @@ class DeepSpeech(nn.Module):
         d_y1 = ops.bn2d_htanh_bwd(sv['y1'], d_a1, sv['mi1'], c[1].weight, c[1].bias, gv(c[1].weight), gv(c[1].bias))
         ops.conv_wgrad(1, sv['xt'], d_y1, t_in, gv(c[0].weight), gv(c[0].bias))
         if side is not None:
-            main.wait_stream(side)
+            main.wait_stream(side)                  # every later consumer of the gradients sits behind this join
+        keepalive.clear()
         if grad_ready is not None:
             grad_ready(*self._span(c[0].weight, c[4].bias))
 
