@@ -267,6 +267,23 @@ class DeepSpeech(nn.Module):
         rows = t * bsz
         layers = []
         prev_h = None
+        if need_grad:
+            # The backward recurrence reads W_hh transposed.  The weights do not change during the step, so the ten
+            # transposes run now, on the side stream, on CUs the forward recurrence leaves idle -- not between
+            # BatchNorm backward and the recurrence kernel of every layer, where they sit on the critical chain.
+            wt = torch.empty((nlayers, 2, hid, 3 * hid), dtype=torch.float32, device=x.device)
+            main = torch.cuda.current_stream()
+            side = self._side_stream(x.device) if self.overlap_wgrad else main
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for li, layer in enumerate(self.rnns):
+                    w_hh = self._pair(layer.rnn.weight_hh_l0, layer.rnn.weight_hh_l0_reverse).view(2, 3 * hid, hid)
+                    ops.transpose2d(w_hh[0], 3 * hid, hid, out=wt[li, 0])
+                    ops.transpose2d(w_hh[1], 3 * hid, hid, out=wt[li, 1])
+                ready = torch.cuda.Event()
+                ready.record()
+            sv['w_hh_t'], sv['w_hh_t_ready'] = wt, ready
         for li, layer in enumerate(self.rnns):
             n_in = self._rnn_input_size if li == 0 else hid
             rec = {}
@@ -339,16 +356,14 @@ class DeepSpeech(nn.Module):
         main = torch.cuda.current_stream()
         side = self._side_stream(gflat.device) if self.overlap_wgrad else None
         keepalive = []
+        main.wait_event(sv['w_hh_t_ready'])
         for li in range(nl - 1, -1, -1):
             rec = sv['layers'][li]
             layer = self.rnns[li]
             r = layer.rnn
             n_in = self._rnn_input_size if li == 0 else hid
             w_ih = self._pair(r.weight_ih_l0, r.weight_ih_l0_reverse)
-            w_hh = self._pair(r.weight_hh_l0, r.weight_hh_l0_reverse).view(2, 3 * hid, hid)
-            w_hh_t = torch.empty((2, hid, 3 * hid), dtype=torch.float32, device=gflat.device)
-            ops.transpose2d(w_hh[0], 3 * hid, hid, out=w_hh_t[0])
-            ops.transpose2d(w_hh[1], 3 * hid, hid, out=w_hh_t[1])
+            w_hh_t = sv['w_hh_t'][li]                                               # transposed during forward
             gates, ghn, hout = rec['gates'], rec['ghn'], rec['hout']
             ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid)           # gates -> d(gi), ghn -> d(gh_n)
             dgi = gates.view(rows, 6 * hid)
