@@ -504,20 +504,33 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                             for (int rg = 0; rg < NRG; ++rg)
                                 acc[rg][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[rg][gi][e], bf[ci][gi][e], acc[rg][ci], 0, 0, 0);
                 // fold the 16 per-block partials: two DPP adds leave each 16-lane row's sum in its lanes 12..15
+                // (all the DPP adds first, as independent chains, then ONE predicated region with the stores: written value
+                // by value the compiler emits add_dpp / s_nop / mov_dpp / saveexec / add / ds_write / restore exec per value)
                 float* rec = red4 + (lane & 3) * RED4_PITCH + wave * 4 + (lane >> 4);
+                float fv[NRG][NCI][4];
 #pragma unroll
                 for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
-                    for (int ci = 0; ci < NCI; ++ci) {
-                        const int cg = c * CGW + ci;
+                    for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) {
-                            float v = acc[rg][ci][rr];
-                            v = dpp_row_shr_add<4>(v);
-                            v = dpp_row_shr_add<8>(v);
-                            if ((lane & 15) >= 12) rec[((rg * ncg + cg) * 4 + rr) * 4 * RED4_PITCH] = v;
+                        for (int rr = 0; rr < 4; ++rr) fv[rg][ci][rr] = dpp_row_shr_add<4>(acc[rg][ci][rr]);
+#pragma unroll
+                for (int rg = 0; rg < NRG; ++rg)
+#pragma unroll
+                    for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) fv[rg][ci][rr] = dpp_row_shr_add<8>(fv[rg][ci][rr]);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((lane & 15) >= 12) {
+#pragma unroll
+                    for (int rg = 0; rg < NRG; ++rg)
+#pragma unroll
+                        for (int ci = 0; ci < NCI; ++ci) {
+                            const int cg = c * CGW + ci;
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) rec[((rg * ncg + cg) * 4 + rr) * 4 * RED4_PITCH] = fv[rg][ci][rr];
                         }
-                    }
+                }
             };
             if (!(dbg & 2)) {
                 const int nfull = ncg / CGW, tail = ncg - nfull * CGW;
