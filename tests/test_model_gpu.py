@@ -215,3 +215,39 @@ def test_beam_decoder_agrees_with_greedy_on_confident_outputs():
         got, offs = BeamCTCDecoder(labels, beam_width=width).decode(probs, sizes)
         assert got == want
         assert all(len(o[0]) == len(g[0]) for o, g in zip(offs, got))
+
+
+@pytest.mark.parametrize('bsz,t_in,label_lens', [(4, 11, [1, 0, 1, 0]), (1, 13, [1]), (3, 29, [2, 0, 1]), (16, 31, [1] * 16)])
+def test_edge_shapes_against_oracle(bsz, t_in, label_lens):
+    """Shortest inputs the conv stack accepts (T_in = 11 -> one output step), a single utterance, empty transcripts,
+    a batch of exactly one 16-row tile: one training step through the fused path against the oracle."""
+    from codes.engine import Trainer
+    kwargs = dict(rnn_hidden_size=32, num_rnn_layers=2, num_classes=29)
+    oracle = OracleDeepSpeech(**kwargs)
+    oracle.load_state_dict(seeded_state_dict(oracle, 21))
+    model = _build(kwargs)
+    model.load_state_dict(seeded_state_dict(oracle, 21))
+    model.to('cuda')
+    opt_o = torch.optim.SGD(oracle.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
+    trainer = Trainer(model, opt, device='cuda', max_norm=400)
+    x = torch.from_numpy(seeded_inputs(7, bsz, t_in))
+    rng = np.random.default_rng(bsz)
+    labels = torch.from_numpy(rng.integers(1, 29, size=max(sum(label_lens), 0)).astype(np.int32))
+    pct = torch.ones(bsz, dtype=torch.float32)
+    sizes = torch.tensor(label_lens, dtype=torch.int32)
+    oracle.train()
+    logits = oracle(x)
+    t_out = logits.shape[1]
+    assert t_out == conv_out_time(t_in)
+    out_sizes = (pct * t_out).int()
+    loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), labels.long(), out_sizes.long(), sizes.long(), blank=0,
+                      reduction='sum') / bsz
+    opt_o.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(oracle.parameters(), 400)
+    opt_o.step()
+    got = trainer.update((x, labels, pct, sizes))
+    assert abs(got - float(loss.item())) <= 2e-4 * max(abs(float(loss.item())), 1.0)
+    for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), atol=5e-5, err_msg=k)
