@@ -177,6 +177,9 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29531')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        # The recurrence kernels need ~204 of the 256 CUs co-resident; cap RCCL's kernels at 32 workgroups so a gradient
+        # all-reduce running beside them (on the 52 CUs they leave free) can never keep one from starting.
+        os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
         dist.init_process_group('nccl', init_method='env://')
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 

@@ -81,6 +81,8 @@ def main(argv=None):
     main_proc = True
     if args.distributed:
         torch.cuda.set_device(device)
+        # the recurrence kernels need ~204 of the 256 CUs co-resident: keep RCCL's kernels at <= 32 workgroups
+        os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
         torch.distributed.init_process_group(backend=args.dist_backend, init_method=args.init_method)
         main_proc = torch.distributed.get_rank() == 0
 
