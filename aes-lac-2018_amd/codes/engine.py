@@ -17,6 +17,7 @@ views of the trainer's flat momentum buffer so ``optimizer.state_dict()`` checkp
 other optimizer falls back to ``loss.backward()`` through the model's autograd node + ``optimizer.step()``.
 """
 import logging
+import os
 import time
 
 import torch
@@ -47,7 +48,7 @@ class Trainer(object):
         self.last_grad_norm = None
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
-        self.overlap = overlap_allreduce and self.distributed
+        self.overlap = overlap_allreduce and self.distributed and os.environ.get('DS2_ALLREDUCE_OVERLAP', '1') != '0'
         self._comm_stream = None
         self._buf = None
         self._first = True

@@ -80,6 +80,9 @@ def main(argv=None):
     device = torch.device('cuda' if args.local else 'cuda:{}'.format(args.local_rank))
     main_proc = True
     if args.distributed:
+        # (see bench.py) three hardware queues serve the main / weight-gradient / all-reduce streams better than the
+        # default four; the HIP runtime reads this at its first call, so it goes before set_device
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '3')
         torch.cuda.set_device(device)
         # the recurrence kernels need ~204 of the 256 CUs co-resident: keep RCCL's kernels at <= 32 workgroups
         os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
