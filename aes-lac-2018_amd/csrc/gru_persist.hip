@@ -224,6 +224,144 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
     }
 }
 
+// Forward recurrence, 16x16x4 form with TWO batch parts (blockIdx.z): a workgroup owns 16 units and half the batch, so
+// its gate rows fill three whole tiles (r16, z16, n16; the 8-unit form above pads its second tile by half) and it loads
+// half the hidden state per step.  For B >= 24: per wave and batch tile 3 x KBW x 4 MFMAs instead of 2 x 2 x KBW x 4 for
+// the two tiles a whole batch of 32 needs.  NBT = batch tiles of 16 per part (1 or 2).
+template <int NBT, int KBW>
+__global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                         float* __restrict__ hout,
+                                                                         const float* __restrict__ w_hh,
+                                                                         SyncWs* __restrict__ sync,
+                                                                         float* __restrict__ ring, int T, int B, int H,
+                                                                         int dbg) {
+    __shared__ float red[NWP][3][NBT][16][17];
+    __shared__ int abort_flag;
+    constexpr int UNITS = 16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
+    const int j0 = blockIdx.x * UNITS;
+    const int m = lane & 15, q = lane >> 4;
+    const int nkb = H >> 4;
+    const int bper = (B + 1) / 2, b0 = part * bper, nb = min(bper, B - b0);
+    if (nb <= 0) return;
+    const int slot_floats = NBT * nkb * 256;
+    float* my_ring = ring + (size_t)(dir * 2 + part) * 2 * slot_floats;
+    if (tid == 0) abort_flag = 0;
+
+    f32x4 wreg[3][KBW];                                 // tile g = gate g of units j0 .. j0 + 15 (row m)
+    {
+        const bool unit_ok = (j0 + m) < H;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const float* row = w_hh + ((size_t)dir * 3 * H + (size_t)g * H + (unit_ok ? j0 + m : 0)) * H;
+#pragma unroll
+            for (int i = 0; i < KBW; ++i) {
+                const int kb = wave + NWP * i;
+                wreg[g][i] = (kb < nkb && unit_ok) ? *reinterpret_cast<const f32x4*>(row + kb * 16 + q * 4)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    // gate role: unit jj, local batch row 16 gbt + nn  (512 threads = 16 units x 32 rows)
+    const int jj = tid & 15, nn = (tid >> 4) & 15, gbt = tid >> 8;
+    const int lb = gbt * 16 + nn, gb = b0 + lb, gj = j0 + jj;
+    const bool gate_ok = (gbt < NBT) && (lb < nb) && (gj < H);
+    float hp = 0.f;
+    unsigned int* shards = &sync->arrive[dir][part][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? s : T - 1 - s;
+        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f, sv_h = 0.f;
+        size_t gbase = 0;
+        if (gate_ok) {                                  // independent of h: issue before the wait
+            gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
+            gi_r = G[gbase];
+            gi_z = G[gbase + H];
+            gi_n = G[gbase + 2 * H];
+        }
+        if (s > 0) {
+            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+                abort_flag = 1;
+            __syncthreads();
+            if (abort_flag) return;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
+            f32x4 bf[2][KBW];
+            auto fetch = [&](int bt, f32x4 (&dst)[KBW]) {
+#pragma unroll
+                for (int i = 0; i < KBW; ++i) {
+                    const int kb = wave + NWP * i;                 // wave-uniform
+                    dst[i] = LOAD_HANDOFF(rsrc, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
+                }
+            };
+            if (!(dbg & 2)) {
+                fetch(0, bf[0]);
+#pragma unroll
+                for (int bt = 0; bt < NBT; ++bt) {
+                    if (bt + 1 < NBT) fetch(bt + 1, bf[(bt + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);             // all loads out before the MFMAs
+                    f32x4 acc[3];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < KBW; ++i) {
+                        if (i == KBW - 1 && wave + NWP * i >= nkb) break;   // all-zero padded k block
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int g = 0; g < 3; ++g)
+                                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g][i][e], bf[bt & 1][i][e], acc[g], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) red[wave][g][bt][4 * q + r][m] = acc[g][r];
+                }
+            }
+        }
+        __syncthreads();
+        if (gate_ok) {
+            float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
+            if (s > 0) {
+#pragma unroll
+                for (int w = 0; w < NWP; ++w) {
+                    gh_r += red[w][0][gbt][jj][nn];
+                    gh_z += red[w][1][gbt][jj][nn];
+                    gh_n += red[w][2][gbt][jj][nn];
+                }
+            }
+            const float r = fast_sigmoid(gi_r + gh_r);
+            const float z = fast_sigmoid(gi_z + gh_z);
+            const float n = fast_tanh(gi_n + r * gh_n);
+            const float h = (1.f - z) * n + z * hp;
+            hp = h;
+            // exchange ring of this (direction, part): [batch tile][k block][k quad 4][16 batch rows][4 k]
+            store_sc1(&my_ring[(size_t)(s & 1) * slot_floats + ((size_t)gbt * nkb + (gj >> 4)) * 256 + ((gj & 15) >> 2) * 64 +
+                               nn * 4 + (gj & 3)], h);
+            sv_h = h;
+            sv_r = r;
+            sv_z = z;
+            sv_n = n;
+            sv_g = gh_n;
+        }
+        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gate_ok) {
+            hout[(((size_t)dir * T + t) * B + gb) * H + gj] = sv_h;
+            G[gbase] = sv_r;
+            G[gbase + H] = sv_z;
+            G[gbase + 2 * H] = sv_n;
+            ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g;
+        }
+    }
+}
+
 template <int NBT, int KBW>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                       const float* __restrict__ hout,
@@ -868,6 +1006,27 @@ bool launch_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh,
 }
 
 template <int NBT>
+bool launch_fwd_persistent_p2(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
+                              int H, int dbg, hipStream_t st) {
+    const int opts[] = {1, 2, 4, 7};
+    const int kbw = pick_kbw(ds2_cdiv(H / 16, NWP), opts, 4);
+    dim3 grid(ds2_cdiv(H, 16), 2, 2), block(NWP * 64);
+#define DS2_FWDP2_CASE(K)                                                                                          \
+    case K:                                                                                                        \
+        hipLaunchKernelGGL((gru_fwd_persistent_p2_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, ring,   \
+                           T, B, H, dbg);                                                                          \
+        return true;
+    switch (kbw) {
+        DS2_FWDP2_CASE(1)
+        DS2_FWDP2_CASE(2)
+        DS2_FWDP2_CASE(4)
+        DS2_FWDP2_CASE(7)
+    }
+#undef DS2_FWDP2_CASE
+    return false;
+}
+
+template <int NBT>
 bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                            SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 4, 8, 19};
@@ -1019,6 +1178,9 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
         else ok = two ? launch_fwd_persistent4<3, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
                       : launch_fwd_persistent4<3, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     }
+    else if ((getenv("DS2_GRU_FWD_P2") ? getenv("DS2_GRU_FWD_P2")[0] == '1' : B >= 17) && B >= 2 && H % 16 == 0)
+        ok = (B + 1) / 2 <= 16 ? launch_fwd_persistent_p2<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
+                               : launch_fwd_persistent_p2<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_fwd_persistent<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else ok = launch_fwd_persistent<4>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
