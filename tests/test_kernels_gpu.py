@@ -379,3 +379,37 @@ def test_clip_sgd_matches_torch(ops):
         assert abs(float(ss.item()) ** 0.5 - float(total)) < 1e-3 * float(total)
         ops.clip_sgd_nesterov(pd, gd, buf, ss, 1.0, 400.0, 3e-4, 0.9, step == 0)
         np.testing.assert_allclose(pd[:n].cpu().numpy(), p.detach().numpy(), atol=2e-6)
+
+
+def test_gru_persistent_lost_arrival_times_out_instead_of_hanging(ops, monkeypatch):
+    """Every spin in the persistent kernels is bounded: with one workgroup's arrival suppressed (DS2_GRU_DBG = 64) the
+    launch ends after the 5 s timeout, the host sees the flag and raises, and the next launch works again."""
+    import time
+    t, bsz, hid = 6, 10, 800
+    torch.manual_seed(0)
+    w_hh = (torch.randn(2, 3 * hid, hid) * 0.02).to(DEV)
+    w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
+    gi = torch.randn(t, bsz, 2, 3 * hid).to(DEV)
+    d_out = torch.randn(t, bsz, hid).to(DEV)
+    monkeypatch.setattr(ops, 'GRU_MODE', 'persistent')
+    g = gi.clone()
+    ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
+    good = (g.clone(), ghn.clone(), hout.clone())
+    for which in ('fwd', 'bwd'):
+        monkeypatch.setenv('DS2_GRU_DBG', '64')
+        t0 = time.time()
+        if which == 'fwd':
+            ops.gru_bidir_fwd(gi.clone(), w_hh, t, bsz, hid)
+        else:
+            ops.gru_bidir_bwd(g.clone(), ghn.clone(), hout, d_out, w_hh_t, t, bsz, hid)
+        torch.cuda.synchronize()
+        assert 3.0 < time.time() - t0 < 60.0
+        with pytest.raises(RuntimeError, match='timed out'):
+            ops.check_async_errors()
+        monkeypatch.setenv('DS2_GRU_DBG', '0')
+        g2 = gi.clone()
+        ghn2, hout2 = ops.gru_bidir_fwd(g2, w_hh, t, bsz, hid)
+        torch.cuda.synchronize()
+        ops.check_async_errors()
+        for a, b in zip((g2, ghn2, hout2), good):
+            assert torch.equal(a, b) or float((a - b).abs().max()) < 1e-6
