@@ -18,7 +18,7 @@ OUT = os.path.join(PKG, 'ds2hip', 'libds2hip.so')
 OBJ = os.path.join(HERE, 'build')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', HERE,
-         '-Wall', '-Wno-unused-function']
+         '-Wall', '-Wno-unused-function'] + os.environ.get('DS2_HIPCC_EXTRA', '').split()   # e.g. -DDS2_TIMING=1
 
 
 def _newer(src, dst, deps):

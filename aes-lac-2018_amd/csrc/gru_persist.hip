@@ -22,6 +22,21 @@
 // grid = 2 * ceil(H/8) <= 240 workgroups of 512 threads.  Every spin is bounded by a wall-clock timeout
 // that raises a flag the host checks (no hang on a lost workgroup).
 // ==========================================================================================================
+#ifdef DS2_TIMING
+// per-phase clock of one workgroup's thread 0 (tools/gru_phase_timing.py builds with -DDS2_TIMING=1)
+__device__ long long ds2_tbuf[32 * 8];
+#define DS2_TICK(i)                                                                                      \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x == 5 && blockIdx.y == 0 && blockIdx.z == 0 && s >= 100 && s < 132) \
+            ds2_tbuf[(s - 100) * 8 + (i)] = __builtin_amdgcn_s_memtime();                                \
+    } while (0)
+extern "C" int ds2_debug_read_timing(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ds2_tbuf), sizeof(long long) * 32 * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define DS2_TICK(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int NWP = 8;                    // waves per persistent workgroup (2 per SIMD)
@@ -587,6 +602,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
+        DS2_TICK(0);
         const int t = dir == 0 ? T - 1 - s : s;
         const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
         float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
@@ -605,7 +621,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         if (s > 0) {
             if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
+            DS2_TICK(1);
             __syncthreads();
+            DS2_TICK(2);
             if (abort_flag) return;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
                 my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
@@ -683,7 +701,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 }
             }
         }
+        DS2_TICK(3);
         __syncthreads();
+        DS2_TICK(4);
         if (gate_ok) {
             if (s > 0) {
                 const int rg = jj >> 2, rr = jj & 3, cg = nn >> 2, bj = nn & 3;
@@ -711,8 +731,11 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             sv_n = dn_pre;
             sv_g = dn_pre * r;
         }
+        DS2_TICK(5);
         if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DS2_TICK(6);
         __syncthreads();
+        DS2_TICK(7);
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
         if (tid == 0 && !((dbg & 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
