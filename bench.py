@@ -294,7 +294,7 @@ def main():
                      'whole_step_tflops_per_gpu': round(step_tflops, 3),
                      'whole_step_frac_of_f32_mfma_peak': round(step_tflops / PEAK_F32_MFMA_TFLOPS, 5)},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU oracle is timed beside the GPU at N = 1 only
         result['cpu_baseline'] = cpu_baseline(plan)
     if use_dist:
         dist.destroy_process_group()
