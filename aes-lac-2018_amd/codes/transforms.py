@@ -92,20 +92,60 @@ class Compose(object):
         return x
 
 
+def wsola_tempo(x, tempo, sample_rate=16000, segment_ms=82.0, search_ms=14.68, overlap_ms=12.0):
+    """Change the tempo of a 1-D float array without changing its pitch (WSOLA: waveform-similarity overlap-add).
+
+    Stands in for ``sox ... tempo <factor>`` (``codes/transforms.py:185-218``), whose defaults are a 82 ms segment,
+    a 14.68 ms search window and a 12 ms overlap.  Output length ~ len(x) / tempo.  The segment that continues the
+    output is looked for around the ideal input position, where it correlates best with the natural continuation of
+    the previous segment, and cross-faded in over the overlap.  Not bit-compatible with sox (nor claimed to be)."""
+    import numpy as np
+    x = np.asarray(x, dtype=np.float32).reshape(-1)
+    if abs(tempo - 1.0) < 1e-6 or x.size == 0:
+        return x.copy()
+    seg = max(int(sample_rate * segment_ms / 1000.0), 4)
+    ovl = max(min(int(sample_rate * overlap_ms / 1000.0), seg // 2), 1)
+    half = max(int(sample_rate * search_ms / 1000.0) // 2, 1)
+    hop_out = seg - ovl
+    hop_in = tempo * hop_out
+    if x.size <= seg + half:
+        return x.copy()
+    fade_in = np.linspace(0.0, 1.0, ovl, endpoint=False, dtype=np.float32)
+    out = np.zeros(int(x.size / tempo) + 2 * seg, dtype=np.float32)
+    out[:seg] = x[:seg]
+    out_pos, prev, ideal = hop_out, 0, 0.0
+    while True:
+        ideal += hop_in
+        base = int(round(ideal))
+        lo, hi = max(base - half, 0), min(base + half, x.size - seg)
+        if hi < lo:
+            break
+        want = x[prev + hop_out: prev + hop_out + ovl]                # how the previous segment would have gone on
+        if want.size < ovl:
+            break
+        window = x[lo: hi + ovl]
+        corr = np.correlate(window, want, mode='valid')                # corr[d] = <x[lo + d : lo + d + ovl], want>
+        start = lo + int(np.argmax(corr))
+        out[out_pos: out_pos + ovl] = out[out_pos: out_pos + ovl] * (1.0 - fade_in) + x[start: start + ovl] * fade_in
+        out[out_pos + ovl: out_pos + seg] = x[start + ovl: start + seg]
+        prev, out_pos = start, out_pos + hop_out
+    return out[: out_pos + ovl]
+
+
 class ToTensor(object):
     """16-bit PCM mono WAV -> 1-D float tensor (reference ``codes/transforms.py:130-224``).
 
-    The reference decodes with torchaudio/sox (absent here) and augments with the ``sox`` CLI (tempo + gain);
-    this loader reads PCM16 with the standard library and scales to [-1, 1).  ``augment=True`` is refused:
-    sox's WSOLA tempo change has no parity target on this box."""
+    The reference decodes with torchaudio/sox (absent here); this loader reads PCM16 with the standard library and
+    scales to [-1, 1).  ``augment=True`` draws a tempo and a gain uniformly from the ranges exactly as the reference
+    does (``np.random.uniform``) and applies them on the host: tempo with ``wsola_tempo`` above, gain in dB, then
+    the clip and 16-bit rounding sox's ``-b 16`` output implies.  sox itself is not available, so the augmented
+    waveform is the same kind of signal, not the same samples."""
 
     def __init__(self, sample_rate=16000, augment=False, tempo_range=(0.85, 1.15), gain_range=(-6, 8)):
-        if augment:
-            raise NotImplementedError('sox tempo/gain augmentation is out of scope (no sox on this box)')
         self.sample_rate, self.augment = sample_rate, augment
         self.tempo_range, self.gain_range = tempo_range, gain_range
 
-    def __call__(self, path):
+    def _load(self, path):
         import wave
 
         import numpy as np
@@ -113,7 +153,22 @@ class ToTensor(object):
             assert w.getframerate() == self.sample_rate, 'sample rate mismatch'
             assert w.getsampwidth() == 2 and w.getnchannels() == 1, 'expected 16-bit mono PCM'
             pcm = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2')
-        return torch.from_numpy(pcm.astype('float32') / 32768.0)
+        return pcm.astype('float32') / 32768.0
+
+    def __call__(self, path):
+        import numpy as np
+        y = self._load(path)
+        if self.augment:
+            tempo = np.random.uniform(low=self.tempo_range[0], high=self.tempo_range[1])
+            gain = np.random.uniform(low=self.gain_range[0], high=self.gain_range[1])
+            y = wsola_tempo(y, float('{:.3f}'.format(tempo)), self.sample_rate)      # sox got three decimals
+            y = y * np.float32(10.0 ** (float('{:.3f}'.format(gain)) / 20.0))
+            y = np.clip(np.round(y * 32768.0), -32768, 32767).astype('float32') / 32768.0
+        return torch.from_numpy(np.ascontiguousarray(y))
+
+    def __repr__(self):
+        return '{}(sample_rate={}, augment={}, tempo_range={}, gain_range={})'.format(
+            self.__class__.__name__, self.sample_rate, self.augment, self.tempo_range, self.gain_range)
 
 
 _ACCENT_FOLD = {'À': 'A', 'Á': 'A', 'Â': 'A', 'Ã': 'A', 'Ä': 'A', 'Ç': 'C', 'È': 'E', 'É': 'E', 'Ê': 'E', 'Ë': 'E',

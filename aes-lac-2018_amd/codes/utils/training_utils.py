@@ -24,12 +24,10 @@ NUM_CLASSES = {'pt_BR': 43, 'en': 29}
 def get_default_transforms(data_dir, config, gpu_frontend=True):
     """Waveform loader (+ per-utterance spectrogram when ``gpu_frontend`` is False) and one ToLabel per language
     (training_utils.py:18-34).  With ``gpu_frontend`` the spectrogram runs batched on the device after collate."""
-    augment = bool(config.training.get('augment', False))
-    if augment:
-        LOG.warning('sox tempo/gain augmentation is not available on this box; training without it')
-    load = transforms.ToTensor(augment=False)
-    chain = [load] if gpu_frontend else [load, transforms.ToSpectrogram(librosa_compat=True)]
-    train_t, val_t = transforms.Compose(chain), transforms.Compose(chain)
+    augment = bool(config.training.get('augment', False))       # tempo + gain on the training set only (WSOLA on the host)
+    tail = [] if gpu_frontend else [transforms.ToSpectrogram(librosa_compat=True)]
+    train_t = transforms.Compose([transforms.ToTensor(augment=augment)] + tail)
+    val_t = transforms.Compose([transforms.ToTensor(augment=False)] + tail)
     target_t = [transforms.ToLabel(os.path.join(data_dir, 'labels.{}.json'.format(lang)), lang=lang,
                                    remove_accents=(lang != 'pt_BR')) for lang in config.model.langs]
     return train_t, val_t, target_t

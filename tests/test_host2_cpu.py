@@ -276,3 +276,39 @@ def test_ctc_prefix_beam_search_host_entry_point():
     assert BeamCTCDecoder(labels, beam_width=8).decode(torch.from_numpy(split), None)[0][0][0] == 'A'
     with pytest.raises(ValueError):
         BeamCTCDecoder(labels, beam_width=0)
+
+
+def test_tempo_and_gain_augmentation(tmp_path):
+    """ToTensor(augment=True): WSOLA tempo keeps the pitch and scales the duration, the gain is in dB, draws follow
+    np.random like the reference's (codes/transforms.py:171-182)."""
+    from codes.transforms import ToTensor, wsola_tempo
+    sr = 16000
+    t = np.arange(3 * sr) / sr
+    tone = (0.2 * np.sin(2 * np.pi * 440.0 * t)).astype(np.float32)
+    for tempo in (0.85, 1.0, 1.15, 1.3):
+        y = wsola_tempo(tone, tempo, sr)
+        assert abs(len(y) - len(tone) / tempo) < 0.1 * sr                     # duration scales by 1 / tempo
+        spec = np.abs(np.fft.rfft(y * np.hanning(len(y))))
+        peak = np.argmax(spec) * sr / len(y)
+        assert abs(peak - 440.0) < 3.0, (tempo, peak)                          # pitch unchanged
+        assert 0.8 < float(np.sqrt(np.mean(y ** 2))) / float(np.sqrt(np.mean(tone ** 2))) < 1.1
+    assert np.array_equal(wsola_tempo(tone, 1.0, sr), tone)
+    noise = np.random.default_rng(0).standard_normal(2 * sr).astype(np.float32) * 0.05
+    y = wsola_tempo(noise, 1.1, sr)
+    assert abs(len(y) - len(noise) / 1.1) < 0.1 * sr and np.isfinite(y).all()
+    path = str(tmp_path / 'a.wav')
+    _write_wav(path, tone)
+    plain = ToTensor()(path)
+    np.random.seed(5)
+    tempo = np.random.uniform(0.85, 1.15)
+    gain = np.random.uniform(-6, 8)
+    np.random.seed(5)
+    aug = ToTensor(augment=True)(path)
+    assert aug.dtype == torch.float32 and aug.ndim == 1
+    assert abs(len(aug) - len(plain) / tempo) < 0.1 * sr
+    ratio = float(aug.pow(2).mean().sqrt() / plain.pow(2).mean().sqrt())
+    assert abs(20 * np.log10(ratio) - gain) < 1.0
+    assert float(aug.abs().max()) <= 1.0
+    np.random.seed(5)
+    assert torch.equal(ToTensor(augment=True)(path), aug)                      # reproducible from the seed
+    assert 'augment=True' in repr(ToTensor(augment=True))
