@@ -32,7 +32,7 @@ def _corpus(tmp_path, n=6):
     cfg = json.load(open(os.path.join(ROOT, 'scripts', 'librispeech-from_scratch.json')))
     cfg['model']['name'] = 'tiny'
     cfg['model']['params'] = {'rnn_hidden_size': 32, 'num_rnn_layers': 2}
-    cfg['training'].update(num_epochs=2, batch_size=3)
+    cfg['training'].update(num_epochs=2, batch_size=3, augment=True)      # tempo + gain on the training set
     (tmp_path / 'tiny.json').write_text(json.dumps(cfg))
 
 
