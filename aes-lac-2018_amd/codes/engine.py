@@ -11,8 +11,9 @@ RCCL over xGMI) the flat gradient is sum-all-reduced in per-layer buckets on a s
 is still running, and the 1/world average folds into the update kernel; BatchNorm statistics stay
 per-replica, as under the reference's DDP (``train.py:172-175``).
 
-The optimizer object is the reference's ``torch.optim.SGD`` (built from the JSON config): learning rate,
-momentum and the LR scheduler keep working through ``optimizer.param_groups``; its momentum buffers are
+The optimizer object is the reference's ``torch.optim.SGD`` (built from the JSON config, with any number of
+parameter groups -- the per-layer learning rates of ``training_utils.py:133-159`` -- and with frozen parameters left
+out): learning rate, momentum and the LR scheduler keep working through ``optimizer.param_groups``; its momentum buffers are
 views of the trainer's flat momentum buffer so ``optimizer.state_dict()`` checkpoints as before.  Any
 other optimizer falls back to ``loss.backward()`` through the model's autograd node + ``optimizer.step()``.
 """
@@ -64,13 +65,39 @@ class Trainer(object):
 
     # ---------------------------------------------------------------- optimizer plumbing
     def _fused_ok(self):
+        """The fused clip + Nesterov-SGD pass covers ``torch.optim.SGD`` with any number of parameter groups (the
+        reference's per-layer learning rates, ``training_utils.py:133-159``) as long as every group is Nesterov
+        momentum without dampening or weight decay; frozen parameters (fine-tuning with ``freeze_layers``) are simply
+        left out of the update.  ``self._spans`` = [(lo, hi, group index)] runs of the flat buffer to update."""
         opt = self.optimizer
-        if not isinstance(opt, torch.optim.SGD) or len(opt.param_groups) != 1:
+        if not isinstance(opt, torch.optim.SGD):
             return False
-        g = opt.param_groups[0]
-        trainable = all(p.requires_grad for p in self.model._plist)
-        return (g.get('nesterov', False) and g.get('momentum', 0) > 0 and g.get('dampening', 0) == 0 and
-                g.get('weight_decay', 0) == 0 and trainable)
+        m = self.model
+        where = {id(p): (o, p.numel()) for p, o in zip(m._plist, m._offsets)}
+        spans, seen = [], set()
+        for gi, g in enumerate(opt.param_groups):
+            if not (g.get('nesterov', False) and g.get('momentum', 0) > 0 and g.get('dampening', 0) == 0 and
+                    g.get('weight_decay', 0) == 0):
+                return False
+            for p in g['params']:
+                if id(p) not in where or id(p) in seen:
+                    return False
+                seen.add(id(p))
+                if not p.requires_grad:
+                    continue
+                o, n = where[id(p)]
+                spans.append((o, o + (n + 3) // 4 * 4, gi))    # parameters are padded to 4 floats in the flat buffer
+        if any(p.requires_grad and id(p) not in seen for p in m._plist):
+            return False                                         # a trainable parameter the optimizer does not know
+        merged = []
+        for lo, hi, gi in sorted(spans):                         # flat order; adjacent runs of one group become one launch
+            hi = min(hi, m._flat_p.numel())
+            if merged and merged[-1][2] == gi and merged[-1][1] == lo:
+                merged[-1] = (merged[-1][0], hi, gi)
+            else:
+                merged.append((lo, hi, gi))
+        self._spans = merged
+        return len(merged) > 0
 
     def _bind_momentum(self):
         """Flat momentum buffer; the torch optimizer's per-parameter state entries are views of it."""
@@ -121,9 +148,10 @@ class Trainer(object):
                 dist.all_reduce(gflat)
         scale = 1.0 / self.world
         self._sumsq = ops.sumsq(gflat, self._sumsq)
-        g = self.optimizer.param_groups[0]
-        ops.clip_sgd_nesterov(model._flat_p, gflat, self._buf, self._sumsq, scale, self.max_norm, g['lr'],
-                              g['momentum'], self._first)
+        for lo, hi, gi in self._spans:                              # one run per parameter group (one in all, usually)
+            g = self.optimizer.param_groups[gi]
+            ops.clip_sgd_nesterov(model._flat_p[lo:hi], gflat[lo:hi], self._buf[lo:hi], self._sumsq, scale,
+                                  self.max_norm, g['lr'], g['momentum'], self._first)
         self._first = False
         # one device->host readback for everything the host needs: loss, grad norm^2, kernel timeout flags
         words = ops.async_error_words()

@@ -251,3 +251,49 @@ def test_edge_shapes_against_oracle(bsz, t_in, label_lens):
     assert abs(got - float(loss.item())) <= 2e-4 * max(abs(float(loss.item())), 1.0)
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), atol=5e-5, err_msg=k)
+
+
+def test_fused_step_with_param_groups_and_frozen_conv():
+    """Fine-tuning shape of the reference (pt_BR-finetune-freeze.json + per-layer learning rates): conv block frozen
+    (its BatchNorm in inference mode, no gradient, no update), rnns and fc in separate groups with their own learning
+    rates -- still on the fused clip + SGD pass, and equal to torch on the oracle."""
+    from codes.engine import Trainer
+    from codes.utils.training_utils import _freeze_layers, get_per_params_lr
+    from codes.utils.io_utils import AttrDict
+    kwargs = dict(rnn_hidden_size=32, num_rnn_layers=2, num_classes=29)
+    oracle = OracleDeepSpeech(**kwargs)
+    oracle.load_state_dict(seeded_state_dict(oracle, 31))
+    model = _build(kwargs)
+    model.load_state_dict(seeded_state_dict(oracle, 31))
+    model.to('cuda')
+    _freeze_layers(model, ['conv'])
+    for p in oracle.conv.parameters():
+        p.requires_grad_(False)
+    conf = AttrDict({'per_layer_lr': [['rnns', 2e-2], ['fc', 5e-3], ['base']]})
+    opt = torch.optim.SGD(get_per_params_lr(model, conf), lr=1e-2, momentum=0.9, nesterov=True)
+    opt_o = torch.optim.SGD([{'params': list(oracle.rnns.parameters()), 'lr': 2e-2},
+                             {'params': list(oracle.fc.parameters()), 'lr': 5e-3},
+                             {'params': list(oracle.conv.parameters())}], lr=1e-2, momentum=0.9, nesterov=True)
+    trainer = Trainer(model, opt, device='cuda', max_norm=3.0)
+    assert trainer._fused and len(trainer._spans) == 2
+    rng = np.random.default_rng(1)
+    for step in range(2):
+        x = torch.from_numpy(seeded_inputs(40 + step, 3, 70))
+        label_lens = [4, 3, 2]
+        labels = torch.from_numpy(rng.integers(1, 29, size=sum(label_lens)).astype(np.int32))
+        pct = torch.ones(3, dtype=torch.float32)
+        sizes = torch.tensor(label_lens, dtype=torch.int32)
+        oracle.train()
+        oracle.conv.eval()                                   # frozen modules keep BatchNorm in inference mode
+        logits = oracle(x)
+        out_sizes = (pct * logits.shape[1]).int()
+        loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), labels.long(), out_sizes.long(), sizes.long(),
+                          blank=0, reduction='sum') / 3
+        opt_o.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in oracle.parameters() if p.requires_grad], 3.0)
+        opt_o.step()
+        got = trainer.update((x, labels, pct, sizes))
+        assert abs(got - float(loss.item())) <= 2e-4 * abs(float(loss.item()))
+        for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), atol=5e-5, err_msg='%s step %d' % (k, step))
