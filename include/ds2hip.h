@@ -141,11 +141,14 @@ int ds2_gru_bidir_bwd(float* G, float* ghn, const float* hout, const float* d_ou
 int ds2_transpose2d(const float* in, int rows, int cols, float* out, void* stream);
 /* Persistent form of the two calls above: ONE launch per layer pass; every workgroup keeps its slice
  * of the recurrent weights in registers for all T steps and hands h_t (forward) / d(gh)_t (backward)
- * to the other workgroups inside the launch as 8-byte {value, epoch} granules (write-through stores
- * polled by their consumers; env DS2_GRU_HANDOFF=counter selects the arrival-counter form instead).
- * Same arguments and results; sync_ws is a caller-owned device buffer of ds2_gru_sync_ws_bytes(B, H)
- * bytes (zeroed by the call).  If a bounded spin times out, the 32-bit word at byte offset
- * ds2_gru_sync_error_offset() of sync_ws is set to 1 (results are then invalid -- check it after
+ * to the other workgroups of its direction (and batch part) inside the launch: write-through stores
+ * into an exchange ring inside sync_ws, one arrival add per workgroup per step on sharded counters,
+ * one polling wave per consumer, write-through-coherent loads straight into MFMA operands.  The form
+ * (4x4x1 or 16x16x4 MFMA, 1-3 batch parts) is chosen from B and H; results do not depend on it beyond
+ * fp32 summation order.  Same arguments and results as the per-step calls; sync_ws is a caller-owned
+ * device buffer of ds2_gru_sync_ws_bytes(B, H) bytes, 16-byte aligned (zeroed by the call).  Every
+ * spin is bounded (5 s): on a timeout the 32-bit word at byte offset ds2_gru_sync_error_offset() of
+ * sync_ws is set to 1 and the launch ends (results are then invalid -- check the word after
  * synchronising).  Returns DS2_ERR_UNSUPPORTED for shapes outside ds2_gru_persistent_supported(B, H)
  * (H % 16 == 0, 2*ceil(H/8) <= 240 co-resident workgroups, B <= 64). */
 size_t ds2_gru_sync_ws_bytes(int B, int H);
