@@ -6,15 +6,17 @@ Reference call sites: ``train.py:12,179`` (``from warpctc_pytorch import CTCLoss
   act_lens / label_lens int32 (B) (CPU or device)  ->  1-element tensor = SUM over the batch of -log p,
   differentiable w.r.t. acts only, blank = 0.
 The arithmetic is ``ds2_ctc_loss_grad`` (csrc/ctc.hip); the gradient is produced in the same pass and
-handed to autograd in backward.  An infeasible utterance contributes +inf, which the trainer zeroes like
-``codes/engine.py:27-30``.
+handed to autograd in backward.  An infeasible utterance contributes +inf (and, like warp-ctc, no gradient of its
+own); the trainer then applies ``codes/engine.py:24-30``: the batch loss becomes ``0 * loss``, i.e. the value is
+reported as 0 and the WHOLE batch's gradient is zero (``zero_batch_if_inf`` does that inside the gradient kernel
+for the fused step; the autograd path gets it from the 0 factor).
 """
 import torch
 
 from ds2hip import ops
 
 
-def ctc_costs_and_grad(acts, labels, act_lens, label_lens, grad_scale=1.0):
+def ctc_costs_and_grad(acts, labels, act_lens, label_lens, grad_scale=1.0, zero_batch_if_inf=False):
     """Raw kernel call: returns (costs (B,), grad (T,B,A)) on the device of ``acts``.
 
     The four small integer arrays the warp-ctc signature passes on the host (labels, lengths) travel to the
@@ -34,7 +36,7 @@ def ctc_costs_and_grad(acts, labels, act_lens, label_lens, grad_scale=1.0):
     packed[nlab + 2 * bsz:] = act_lens_c
     d = ops.upload_small(packed, dev)
     return ops.ctc_loss_grad(acts.contiguous().float(), d[:nlab], d[nlab:nlab + bsz], d[nlab + bsz:nlab + 2 * bsz],
-                             d[nlab + 2 * bsz:], max_len, grad_scale)
+                             d[nlab + 2 * bsz:], max_len, grad_scale, zero_batch_if_inf)
 
 
 class _CTCFunction(torch.autograd.Function):

@@ -54,11 +54,13 @@ class Trainer(object):
         self._buf = None
         self._first = True
         self._sumsq = None
+        self._stats = None
         model._ensure_flat()
         if self.distributed:                     # DDP construction: rank 0's parameters and buffers win
             dist.broadcast(model._flat_p, 0)
             for b in model.buffers():
-                dist.broadcast(b, 0)
+                if b.is_cuda:                    # (num_batches_tracked counters live on the host)
+                    dist.broadcast(b, 0)
         self._fused = self._fused_ok()
         if self._fused:
             self._bind_momentum()
@@ -135,7 +137,8 @@ class Trainer(object):
 
         def loss_fn(acts):
             out_sizes = sanitize_inputs(acts.shape[0], input_percentages)
-            costs, d_acts = ctc_costs_and_grad(acts, targets, out_sizes, target_sizes, grad_scale=1.0 / bsz)
+            costs, d_acts = ctc_costs_and_grad(acts, targets, out_sizes, target_sizes, grad_scale=1.0 / bsz,
+                                               zero_batch_if_inf=True)      # codes/engine.py:24-30
             return costs, d_acts
 
         hook = self._bucket_hook() if self.overlap else None
@@ -153,19 +156,21 @@ class Trainer(object):
             ops.clip_sgd_nesterov(model._flat_p[lo:hi], gflat[lo:hi], self._buf[lo:hi], self._sumsq, scale,
                                   self.max_norm, g['lr'], g['momentum'], self._first)
         self._first = False
-        # one device->host readback for everything the host needs: loss, grad norm^2, kernel timeout flags
-        words = ops.async_error_words()
-        stats = torch.cat([costs.sum().double().reshape(1) / bsz, self._sumsq] + [w.double() for w in words])
-        host, done = ops.download_small(stats)                            # async copy into pinned memory
+        # one launch gathers what the host needs (loss sum, grad norm^2, sticky kernel-timeout flags, inf count),
+        # one device->host copy brings it over
+        self._stats = ops.step_stats(costs, self._sumsq, self._stats)
+        host, done = ops.download_small(self._stats)                      # async copy into pinned memory
         ops.spin_wait(done)                                               # the step's one sync (codes/engine.py:92)
-        stats = host.tolist()
-        if any(v != 0 for v in stats[2:]):
+        loss_sum, sumsq, timed_out, n_inf = host.tolist()
+        if timed_out != 0:
             ops.raise_async_error()
         self.iteration += 1
-        loss_v = float(stats[0])
-        self.last_grad_norm = float(stats[1]) ** 0.5 * scale
-        if loss_v in (float('inf'), float('-inf')):
-            LOG.warning('WARNING: received an inf loss, setting loss value to 0')   # codes/engine.py:27-30
+        self.last_grad_norm = float(sumsq) ** 0.5 * scale
+        loss_v = float(loss_sum) / bsz
+        if n_inf != 0 or loss_v in (float('inf'), float('-inf')):
+            # codes/engine.py:27-30: the loss becomes 0 * loss -- reported as 0, and no utterance of the batch contributed
+            # a gradient (the CTC kernel zeroed it); the update above ran on momentum alone, as optimizer.step() does
+            LOG.warning('WARNING: received an inf loss, setting loss value to 0')
             loss_v = 0.0
         return loss_v
 
@@ -199,10 +204,10 @@ class Trainer(object):
         out_sizes = sanitize_inputs(out.shape[1], input_percentages)
         loss = self.criterion(out.transpose(0, 1), targets, out_sizes, target_sizes) / inputs.shape[0]
         loss = loss.sum()
-        if float(loss.item()) in (float('inf'), float('-inf')):
+        is_inf = float(loss.item()) in (float('inf'), float('-inf'))
+        if is_inf:                                   # codes/engine.py:27-30: 0 * loss -> a zero gradient, the step still runs
             LOG.warning('WARNING: received an inf loss, setting loss value to 0')
-            self.optimizer.zero_grad()
-            return 0.0
+            loss = 0 * loss
         self.optimizer.zero_grad()
         loss.backward()
         if self.world > 1:
@@ -213,8 +218,9 @@ class Trainer(object):
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
         self.optimizer.step()
         torch.cuda.synchronize()
+        ops.check_async_errors()
         self.iteration += 1
-        return float(loss.item())
+        return 0.0 if is_inf else float(loss.item())
 
     def run(self, loader, num_epochs=1, on_iteration=None, on_epoch=None):
         for epoch in range(num_epochs):
@@ -263,6 +269,7 @@ class Evaluator(object):
                     w, c = self.decoder.wer(hyp, ref), self.decoder.cer(hyp, ref)
                     wer_sum += w / nw if nw else w
                     cer_sum += c / nc if nc else c
+        ops.check_async_errors()                     # (every .item() above synchronised; the timeout flags are sticky)
         n = max(n_utt, 1)
         return {'ctcloss': tot_loss / n, 'wer': 100.0 * wer_sum / n, 'cer': 100.0 * cer_sum / n}
 

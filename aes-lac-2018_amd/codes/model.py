@@ -51,6 +51,13 @@ class _BatchNormParams(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
+    def _apply(self, fn, *args, **kwargs):
+        """``num_batches_tracked`` is bookkeeping the kernels never read: it stays on the HOST whatever device the
+        module moves to, so bumping it after a training forward is a host add, not a kernel launch (7 per step)."""
+        out = super()._apply(fn, *args, **kwargs)
+        self._buffers['num_batches_tracked'] = self._buffers['num_batches_tracked'].to('cpu')
+        return out
+
 
 class _Placeholder(nn.Module):
     """Keeps the reference's Sequential indices (Hardtanh slots hold no parameters)."""

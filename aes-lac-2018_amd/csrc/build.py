@@ -5,6 +5,11 @@
 
 Each .hip file is compiled to an object (cached by mtime) and linked into
 aes-lac-2018_amd/ds2hip/libds2hip.so.  The .so is git-ignored but travels to the GPU box.
+
+A second library, libds2hip_faultinject.so, differs in ONE object: gru_persist.hip compiled with
+-DDS2_FAULT_INJECT=1, which lets DS2_GRU_DBG=64 drop a workgroup's arrival.  Only
+tests/fault_inject_worker.py loads it (the bounded-spin / sticky-flag / fall-back test); the release library
+never reads that variable.
 """
 import os
 import subprocess
@@ -15,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, 'ds2hip', 'libds2hip.so')
+OUT_FI = os.path.join(PKG, 'ds2hip', 'libds2hip_faultinject.so')
 OBJ = os.path.join(HERE, 'build')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', HERE,
@@ -41,6 +47,11 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _newer(src, obj, deps):
             jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
+    fi_src = os.path.join(HERE, 'gru_persist.hip')
+    fi_obj = os.path.join(OBJ, 'gru_persist_faultinject.o')
+    fi_new = force or _newer(fi_src, fi_obj, deps)
+    if fi_new:
+        jobs.append([HIPCC] + FLAGS + ['-DDS2_FAULT_INJECT=1', '-c', fi_src, '-o', fi_obj])
 
     def run(cmd):
         if verbose:
@@ -55,6 +66,9 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(OUT):
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    if jobs or force or not os.path.exists(OUT_FI):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT_FI] +
+            [fi_obj if o.endswith(os.sep + 'gru_persist.o') else o for o in objs])
     return OUT
 
 

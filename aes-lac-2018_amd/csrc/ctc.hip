@@ -183,13 +183,22 @@ __global__ __launch_bounds__(128) void ctc_grad_kernel(const float* __restrict__
                                                        int smax, const double* __restrict__ alpha,
                                                        const double* __restrict__ beta,
                                                        const double* __restrict__ ll_in, float grad_scale,
-                                                       float* __restrict__ grad) {
+                                                       int zero_batch_if_inf, float* __restrict__ grad) {
     __shared__ float occ[256];
+    __shared__ int any_inf;
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     float* grow = grad + ((size_t)t * B + b) * A;
     const int tl = min(act_lens[b], T);
     const double ll = ll_in[b];
-    if (t >= tl || ll == NEG_INF_D) {
+    if (zero_batch_if_inf) {   // the training step's rule (codes/engine.py:27-30): an infinite batch loss is replaced by
+                               // 0 * loss, so NO utterance of the batch contributes a gradient
+        if (tid == 0) any_inf = 0;
+        __syncthreads();
+        for (int i = tid; i < B; i += 128)
+            if (ll_in[i] == NEG_INF_D || ll_in[i] == -NEG_INF_D) any_inf = 1;
+        __syncthreads();
+    }
+    if (t >= tl || ll == NEG_INF_D || (zero_batch_if_inf && any_inf)) {
         for (int k = tid; k < A; k += 128) grow[k] = 0.f;
         return;
     }
@@ -229,8 +238,8 @@ extern "C" size_t ds2_ctc_ws_bytes(int T, int B, int A, int max_label_len) {
 
 extern "C" int ds2_ctc_loss_grad(const float* acts, const int32_t* labels, const int32_t* label_offsets,
                                  const int32_t* label_lens, const int32_t* act_lens, int T, int B, int A,
-                                 int max_label_len, float grad_scale, float* costs, float* grad, void* ws,
-                                 void* stream) {
+                                 int max_label_len, float grad_scale, int zero_batch_if_inf, float* costs,
+                                 float* grad, void* ws, void* stream) {
     DS2_CHECK_ARG(acts && labels && label_offsets && label_lens && act_lens && costs && grad && ws);
     DS2_CHECK_ARG(T > 0 && B > 0 && A > 1 && A <= 256 && max_label_len >= 0);
     const int smax = 2 * max_label_len + 1;
@@ -245,7 +254,7 @@ extern "C" int ds2_ctc_loss_grad(const float* acts, const int32_t* labels, const
     hipLaunchKernelGGL(ctc_alphabeta_kernel, dim3(B, 2), dim3(CTC_THREADS), 0, st, acts, lse, labels, label_offsets,
                        label_lens, act_lens, T, B, A, smax, alpha, beta, ll, costs);
     hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(128), 0, st, acts, lse, labels, label_offsets, label_lens,
-                       act_lens, T, B, A, smax, alpha, beta, ll, grad_scale, grad);
+                       act_lens, T, B, A, smax, alpha, beta, ll, grad_scale, zero_batch_if_inf, grad);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }

@@ -2,6 +2,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "ds2_common.h"
@@ -49,10 +50,36 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NSHARD = 8;  // arrival counters per direction (workgroup x -> shard x % 8), each on its own 128-B line:
                            // 100 arrivals on ONE word serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
-struct SyncWs {            // lives in caller-provided device memory, zeroed before every launch
+struct SyncWs {            // lives in caller-provided device memory: zeroed ONCE by the caller when it is allocated (and
+                           // again after a reported timeout); every launch that completes leaves the counters zero
     unsigned int arrive[2][3][NSHARD][32];   // [direction][batch part (backward batch-split forms)][shard][line]
-    unsigned int error;    // set to 1 on a spin timeout
+    unsigned int done[32];   // workgroups that have left the kernel; the last one zeroes arrive[] and done for the next launch
+    unsigned int error;      // set to 1 on a spin timeout; STICKY: only the host clears it (ops.raise_async_error)
 };
+
+// Diagnostics that change results (skip the arrival wait / the MFMAs / the store drain, lose an arrival) exist only in
+// builds made with -DDS2_TIMING=1 or -DDS2_FAULT_INJECT=1 (tools/gru_*_timing.py, the lost-arrival test's library):
+// the release library never reads DS2_GRU_DBG.
+#if defined(DS2_TIMING) || defined(DS2_FAULT_INJECT)
+#define DS2_DBG(dbg, bit) ((dbg) & (bit))
+#else
+#define DS2_DBG(dbg, bit) 0
+#endif
+
+// Called by thread 0 of every workgroup that leaves the kernel normally (not on the timeout path: there the host resets
+// the workspace).  The arrival adds of this workgroup have been performed at the memory side once vmcnt is 0; the
+// workgroup whose add to `done` comes last knows every other workgroup has stopped polling and adding, and zeroes the
+// counters with write-through stores: the next launch on the stream starts from zero without a memset in between.
+__device__ __forceinline__ void leave_kernel(SyncWs* sync) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned int prev = __hip_atomic_fetch_add(&sync->done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == total - 1) {
+        unsigned int* a = &sync->arrive[0][0][0][0];
+        for (int i = 0; i < 2 * 3 * NSHARD; ++i) __hip_atomic_store(a + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync->done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */);
@@ -150,7 +177,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             gi_n = G[gbase + 2 * H];
         }
         if (s > 0) {
-            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
@@ -169,12 +196,13 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
 #pragma unroll
                 for (int i = 0; i < KBW; ++i) {
                     const int kb = wave + NWP * i;                 // wave-uniform
-                    // rows of padding batch entries are never written and stay zero (the ring is zeroed per launch)
+                    // rows of padding batch entries hold whatever an earlier launch left: their products land in
+                    // output columns >= B, which no gate thread reads
                     // k blocks past the end: an offset beyond the descriptor's range reads as zero, with no branch
                     dst[i] = LOAD_HANDOFF(rsrc, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
                 }
             };
-            if (!(dbg & 2)) {
+            if (!DS2_DBG(dbg, 2)) {
                 fetch(0, bf[0]);
 #pragma unroll
                 for (int bt = 0; bt < NBT; ++bt) {
@@ -226,7 +254,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             sv_n = n;
             sv_g = gh_n;
         }
-        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
+        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // saved activations are only read by later launches: keep them off the hand-off's critical path
@@ -237,6 +265,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g;
         }
     }
+    if (tid == 0) leave_kernel(sync);
 }
 
 // Forward recurrence, 16x16x4 form with TWO batch parts (blockIdx.z): a workgroup owns 16 units and half the batch, so
@@ -261,7 +290,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* 
     const int m = lane & 15, q = lane >> 4;
     const int nkb = H >> 4;
     const int bper = (B + 1) / 2, b0 = part * bper, nb = min(bper, B - b0);
-    if (nb <= 0) return;
+    if (nb <= 0) {
+        if (tid == 0) leave_kernel(sync);
+        return;
+    }
     const int slot_floats = NBT * nkb * 256;
     float* my_ring = ring + (size_t)(dir * 2 + part) * 2 * slot_floats;
     if (tid == 0) abort_flag = 0;
@@ -300,7 +332,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* 
             gi_n = G[gbase + 2 * H];
         }
         if (s > 0) {
-            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
@@ -314,7 +346,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* 
                     dst[i] = LOAD_HANDOFF(rsrc, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
                 }
             };
-            if (!(dbg & 2)) {
+            if (!DS2_DBG(dbg, 2)) {
                 fetch(0, bf[0]);
 #pragma unroll
                 for (int bt = 0; bt < NBT; ++bt) {
@@ -364,7 +396,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* 
             sv_n = n;
             sv_g = gh_n;
         }
-        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {
@@ -375,6 +407,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* 
             ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g;
         }
     }
+    if (tid == 0) leave_kernel(sync);
 }
 
 template <int NBT, int KBW>
@@ -434,7 +467,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
             if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
         }
         if (s > 0) {
-            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
@@ -460,7 +493,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
                         dst[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
-            if (!(dbg & 2)) {
+            if (!DS2_DBG(dbg, 2)) {
                 fetch(0, bf[0]);
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -507,7 +540,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
             sv_n = dn_pre;
             sv_g = dn_pre * r;
         }
-        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
@@ -517,6 +550,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
             ghn[row * H + gj] = sv_g;
         }
     }
+    if (tid == 0) leave_kernel(sync);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -579,7 +613,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     const int ng = (K + 63) >> 6;                       // 64-wide k groups
     const int slot_floats = ng * 64 * nb;               // a partial last quad keeps only its nb & 3 rows
     float* my_ring = ring + (size_t)(dir * NPART + part) * 2 * ((size_t)ng * 64 * bper);
-    if (nb <= 0) return;                                // an empty batch part: nobody waits for it
+    if (nb <= 0) {                                      // an empty batch part: nobody waits for it
+        if (tid == 0) leave_kernel(sync);
+        return;
+    }
     if (tid == 0) abort_flag = 0;
 
     f32x4 wA[NRG][NGI];                                 // weights of unit 4 rg + li at k = 64 G + 4 kk .. +3
@@ -619,7 +656,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
         }
         if (s > 0) {
-            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
             DS2_TICK(1);
             __syncthreads();
@@ -688,7 +725,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                         }
                 }
             };
-            if (!(dbg & 2)) {
+            if (!DS2_DBG(dbg, 2)) {
                 const int nfull = ncg / CGW, tail = ncg - nfull * CGW;
 #pragma unroll 1
                 for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGW>{});
@@ -732,12 +769,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             sv_g = dn_pre * r;
         }
         DS2_TICK(5);
-        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DS2_TICK(6);
         __syncthreads();
         DS2_TICK(7);
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
-        if (tid == 0 && !((dbg & 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
+        if (tid == 0 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
             G[gbase] = sv_r;
@@ -746,6 +783,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             ghn[row * H + gj] = sv_g;
         }
     }
+    if (tid == 0) leave_kernel(sync);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -799,7 +837,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     const int bper = (B + P - 1) / P;
     const int b0 = bpart * bper;
     const int nb = min(bper, B - b0);
-    if (nb <= 0) return;
+    if (nb <= 0) {
+        if (tid == 0) leave_kernel(sync);
+        return;
+    }
     const int ncg = (nb + 3) >> 2;
     const int ng = (H + 63) >> 6;
     const int slot_floats = ng * 64 * nb;
@@ -858,7 +899,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
             }
         }
         if (s > 0) {
-            if (!(dbg & 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
             __syncthreads();
             if (abort_flag) return;
@@ -933,7 +974,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                     }
                 }
             };
-            if (!(dbg & 2)) {
+            if (!DS2_DBG(dbg, 2)) {
                 const int nfull = ncg / CGW, tail = ncg - nfull * CGW;
 #pragma unroll 1
                 for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGW>{});
@@ -983,10 +1024,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 sv_g[bt] = gh_n;
             }
         }
-        if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
+        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
         __syncthreads();
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
-        if (tid == 0 && !((dbg & 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
+        if (tid == 0 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {   // saved activations: read by later launches only, off the critical path
@@ -1003,6 +1044,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
             }
         }
     }
+    if (tid == 0) leave_kernel(sync);
 }
 
 inline int pick_kbw(int need, const int* opts, int nopts) {
@@ -1019,6 +1061,7 @@ bool launch_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh,
     dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
 #define DS2_FWD_CASE(K)                                                                                              \
     case K:                                                                                                          \
+        if (!grid_is_coresident(&gru_fwd_persistent_kernel<NBT, K>, grid, 0)) return false;                          \
         hipLaunchKernelGGL((gru_fwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, ring, T, B,  \
                            H, dbg);                                                                                   \
         return true;
@@ -1040,6 +1083,7 @@ bool launch_fwd_persistent_p2(float* G, float* ghn, float* hout, const float* w_
     dim3 grid(ds2_cdiv(H, 16), 2, 2), block(NWP * 64);
 #define DS2_FWDP2_CASE(K)                                                                                          \
     case K:                                                                                                        \
+        if (!grid_is_coresident(&gru_fwd_persistent_p2_kernel<NBT, K>, grid, 0)) return false;                     \
         hipLaunchKernelGGL((gru_fwd_persistent_p2_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, ring,   \
                            T, B, H, dbg);                                                                          \
         return true;
@@ -1061,6 +1105,7 @@ bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float*
     dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
 #define DS2_BWD_CASE(K)                                                                                          \
     case K:                                                                                                      \
+        if (!grid_is_coresident(&gru_bwd_persistent_kernel<NBT, K>, grid, 0)) return false;                      \
         hipLaunchKernelGGL((gru_bwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, \
                            sync, ring, T, B, H, dbg);                                                            \
         return true;
@@ -1089,6 +1134,7 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
             hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, P, NBT>),           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
+        if (!grid_is_coresident(&gru_fwd_persistent4_kernel<K, P, NBT>, grid, lds)) return false;                \
         hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, P, NBT>), grid, block, lds, st, G, ghn, hout, w_hh, sync,    \
                            ring, T, B, H, dbg);                                                                  \
         return true;
@@ -1116,6 +1162,7 @@ bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float
             hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K, NRG>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
+        if (!grid_is_coresident(&gru_bwd_persistent4_kernel<K, NRG>, grid, lds)) return false;                   \
         hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K, NRG>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t,    \
                            sync, ring, T, B, H, dbg);                                                            \
         return true;
@@ -1129,18 +1176,69 @@ bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float
     return false;
 }
 
+// Co-residency: every workgroup of a persistent launch spins on arrivals from all the others, so the whole grid must be
+// on the chip at once.  The budget is 15/16 of the CURRENT device's compute units (240 of an MI355X's 256: the rest
+// stays free for a concurrent RCCL kernel or the side stream), read once per device; a partitioned (CPX) or smaller
+// device simply answers "unsupported" and the caller uses the per-step kernels.
+inline int device_cus() {
+    static int cus[64] = {0};                          // immutable once filled; a race writes the same value twice
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+inline int max_persistent_wgs() {
+    const int n = device_cus();
+    return n - n / 16;
+}
+
+// Launch-time check of the kernel actually chosen: blocks per CU for its register / LDS footprint x CUs >= grid.
+// Answers are cached per (kernel, LDS bytes, device) -- the occupancy query costs tens of microseconds.
+template <typename K>
+inline bool grid_is_coresident(K kernel, dim3 grid, size_t lds) {
+    struct Entry { const void* k; size_t lds; int dev; int per_cu; };
+    static Entry cache[64];
+    static int ncache = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    int per_cu = -1;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (int i = 0; i < ncache; ++i)
+            if (cache[i].k == key && cache[i].lds == lds && cache[i].dev == dev) per_cu = cache[i].per_cu;
+        if (per_cu < 0) {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NWP * 64, lds) != hipSuccess) n = 0;
+            per_cu = n;
+            if (ncache < 64) cache[ncache++] = Entry{key, lds, dev, n};
+        }
+    }
+    return (long)grid.x * grid.y * grid.z <= (long)per_cu * device_cus();
+}
+
 inline bool persistent_ok(int B, int H) {
-    return (H % 16 == 0) && (2 * ds2_cdiv(H, PJU) <= 240) && (B <= 64) && (ds2_cdiv(3 * H / 16, NWP) <= 19) &&
-           (ds2_cdiv(H / 16, NWP) <= 7);
+    return (H % 16 == 0) && (2 * ds2_cdiv(H, PJU) <= max_persistent_wgs()) && (B <= 64) &&
+           (ds2_cdiv(3 * H / 16, NWP) <= 19) && (ds2_cdiv(H / 16, NWP) <= 7);
 }
 
 inline size_t header_bytes() { return ((sizeof(SyncWs) + 255) / 256) * 256; }
 
-// timing-only diagnostics (results are WRONG when set): DS2_GRU_DBG bit0 = do not wait for arrivals,
-// bit1 = skip the h loads + MFMAs, bit2 = skip the store drain
+// diagnostics (results are WRONG when set): DS2_GRU_DBG bit0 = do not wait for arrivals, bit1 = skip the h loads +
+// MFMAs, bit2 = skip the store drain, bit6 = workgroup 0 loses its arrival of step 2.  Compiled in only with
+// -DDS2_TIMING=1 / -DDS2_FAULT_INJECT=1; the release library ignores the variable.
 inline int dbg_flags() {
+#if defined(DS2_TIMING) || defined(DS2_FAULT_INJECT)
     const char* e = getenv("DS2_GRU_DBG");
     return e ? atoi(e) : 0;
+#else
+    return 0;
+#endif
 }
 
 }  // namespace
@@ -1173,8 +1271,9 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     hipStream_t st = (hipStream_t)stream;
     SyncWs* sync = (SyncWs*)sync_ws;
     float* ring = (float*)((char*)sync_ws + header_bytes());
-    // counters AND ring are zeroed: padding batch rows of the ring must read as 0
-    DS2_HIP(hipMemsetAsync(sync_ws, 0, header_bytes() + ring_floats(B, H) * sizeof(float), st));
+    // No memset: the previous launch left the counters zero (leave_kernel) and nothing reads ring bytes that this
+    // launch has not written, except the padding batch columns of the 16x16x4 forms, whose products land in output
+    // columns no gate thread reads.
     const int dbg = dbg_flags();
     bool ok;
     // Form by batch size.  Measured (H = 800, us per step, 4x4x1 broadcast form with the whole batch per workgroup vs
@@ -1191,7 +1290,7 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
         if (parts > B) parts = B;
         // gate-role capacity: two passes of 512 / (4 * 8 parts) batch rows per workgroup; all workgroups co-resident
         while (parts < 3 && ds2_cdiv(B, parts) > 2 * (NWP * 64 / (32 * parts))) ++parts;
-        if (2 * ds2_cdiv(H, 8 * parts) * parts > 240) parts = 1;
+        if (2 * ds2_cdiv(H, 8 * parts) * parts > max_persistent_wgs()) parts = 1;
     }
     const int bper = ds2_cdiv(B, parts), rpp = NWP * 64 / (32 * parts);
     const bool fits4 = ngi_ok && bper <= 2 * rpp && (size_t)((bper + 3) / 4) * 4 * 24 * parts * FWD4_PITCH * 4 <= 140 * 1024;
@@ -1211,7 +1310,10 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     else if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_fwd_persistent<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     else ok = launch_fwd_persistent<4>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
-    DS2_CHECK_ARG(ok);
+    if (!ok) {
+        ds2_set_error("ds2_gru_bidir_fwd_persistent: the chosen kernel's grid is not co-resident on this device (B=%d H=%d)", B, H);
+        return DS2_ERR_UNSUPPORTED;
+    }
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }
@@ -1227,7 +1329,6 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     hipStream_t st = (hipStream_t)stream;
     SyncWs* sync = (SyncWs*)sync_ws;
     float* ring = (float*)((char*)sync_ws + header_bytes());
-    DS2_HIP(hipMemsetAsync(sync_ws, 0, header_bytes() + ring_floats(B, H) * sizeof(float), st));
     const int dbg = dbg_flags();
     bool ok;
     const char* form = getenv("DS2_GRU_BWD");   // "16" selects the 16x16x4 MFMA form (A/B timing); default: 4x4x1
@@ -1239,7 +1340,7 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     {
         double best = 1e30;
         for (int p = 1; p <= 3; ++p) {
-            if (p > B || 2 * ds2_cdiv(H, 8 * p) * p > 240 || ds2_cdiv(B, p) * 8 * p > NWP * 64) continue;
+            if (p > B || 2 * ds2_cdiv(H, 8 * p) * p > max_persistent_wgs() || ds2_cdiv(B, p) * 8 * p > NWP * 64) continue;
             const int bper = ds2_cdiv(B, p), quads = (bper + 3) / 4;
             const double cost = 0.40 * quads * p + 0.34 * bper / 4.0 + (p == 3 && quads > 2 ? 0.3 : 0.0);
             if (cost < best - 1e-9) {
@@ -1260,7 +1361,10 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-    DS2_CHECK_ARG(ok);
+    if (!ok) {
+        ds2_set_error("ds2_gru_bidir_bwd_persistent: the chosen kernel's grid is not co-resident on this device (B=%d H=%d)", B, H);
+        return DS2_ERR_UNSUPPORTED;
+    }
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }

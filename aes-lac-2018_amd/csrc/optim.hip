@@ -74,7 +74,41 @@ __global__ __launch_bounds__(256) void clip_sgd_kernel(float* __restrict__ p, co
         }
 }
 
+__global__ __launch_bounds__(64) void step_stats_kernel(const float* __restrict__ costs, int B,
+                                                        const double* __restrict__ sumsq,
+                                                        const uint32_t* const* __restrict__ err_words, int n_err,
+                                                        double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    double s = 0.0, ninf = 0.0;
+    for (int i = lane; i < B; i += 64) {
+        const float c = costs[i];
+        s += (double)c;
+        if (isinf(c)) ninf += 1.0;
+    }
+    s = wave_sum_d(s);
+    ninf = wave_sum_d(ninf);
+    double e = 0.0;
+    for (int i = lane; i < n_err; i += 64)
+        if (__hip_atomic_load(err_words[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) e = 1.0;
+    e = wave_sum_d(e);
+    if (lane == 0) {
+        out[0] = s;
+        out[1] = sumsq ? sumsq[0] : 0.0;
+        out[2] = e > 0.0 ? 1.0 : 0.0;
+        out[3] = ninf;
+    }
+}
+
 }  // namespace
+
+extern "C" int ds2_step_stats(const float* costs, int B, const double* sumsq, const uint32_t* const* err_words,
+                              int n_err, double* out, void* stream) {
+    DS2_CHECK_ARG(costs && out && B > 0 && n_err >= 0 && (n_err == 0 || err_words));
+    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, costs, B, sumsq, err_words, n_err,
+                       out);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}
 
 extern "C" size_t ds2_sumsq_ws_bytes(size_t n) {
     (void)n;

@@ -17,7 +17,7 @@ _F = ctypes.c_float
 _P = ctypes.c_void_p
 _Z = ctypes.c_size_t
 
-# name -> (restype, argtypes); tests/test_abi.py checks this table against include/ds2hip.h
+# name -> (restype, argtypes); tests/test_host_cpu.py checks this table against include/ds2hip.h and the .so
 SIGNATURES = {
     'ds2_last_error': (ctypes.c_char_p, []),
     'ds2_version': (_I, []),
@@ -48,10 +48,11 @@ SIGNATURES = {
     'ds2_argmax_rows': (_I, [_P, _I, _I, _P, _P]),
     'ds2_greedy_collapse': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'ds2_ctc_ws_bytes': (_Z, [_I, _I, _I, _I]),
-    'ds2_ctc_loss_grad': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
+    'ds2_ctc_loss_grad': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P]),
     'ds2_sumsq_ws_bytes': (_Z, [_Z]),
     'ds2_sumsq': (_I, [_P, _Z, _P, _P, _P]),
     'ds2_clip_sgd_nesterov': (_I, [_P, _P, _P, _Z, _P, _F, _F, _F, _F, _I, _P]),
+    'ds2_step_stats': (_I, [_P, _I, _P, _P, _I, _P, _P]),
     'ds2_add2': (_I, [_P, _P, _Z, _P, _P]),
     'ds2_stream_create': (_I, [_I, _P]),
     'ds2_stream_destroy': (_I, [_P]),
@@ -60,6 +61,16 @@ SIGNATURES = {
 }
 
 _lib = None
+
+ERR_ARG, ERR_LAUNCH, ERR_UNSUPPORTED = -1, -2, -3           # DS2_ERR_* of include/ds2hip.h
+
+
+class Ds2Error(RuntimeError):
+    """A non-zero status from an entry point; ``code`` is the DS2_ERR_* value."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
 
 
 def load():
@@ -105,7 +116,7 @@ def call(name, *args):
     rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) and a.is_cuda and a.is_contiguous() else _ptr(a)
               for a in args], torch.cuda.current_stream().cuda_stream)
     if rc != 0:
-        raise RuntimeError('%s failed (%d): %s' % (name, rc, load().ds2_last_error().decode()))
+        raise Ds2Error(rc, '%s failed (%d): %s' % (name, rc, load().ds2_last_error().decode()))
 
 
 def host_call(name, *args):

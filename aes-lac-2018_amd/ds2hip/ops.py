@@ -229,40 +229,65 @@ def bn1d_bwd(xa, xb, dy, mi, gamma, rows, feat, dgamma, dbeta):
 # ----------------------------------------------------------------------------- GRU recurrence
 GRU_MODE = os.environ.get('DS2_GRU_MODE', 'auto')     # 'auto' | 'persistent' | 'step'
 _sync_ws = {}
+_persistent_off = {}                                  # device key -> reason: that device runs the per-step kernels from now on
+
+
+def _dev_key(dev):
+    return (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
 
 
 def _gru_sync_ws(dev, bsz, hid):
-    """Per-device hand-off workspace of the persistent recurrence (caller-owned, grown on demand, reused)."""
-    key = (dev.type, dev.index)
+    """Per-device hand-off workspace of the persistent recurrence (caller-owned, grown on demand, reused).  It is
+    zeroed HERE, once: a launch that completes leaves its counters zero for the next one (include/ds2hip.h)."""
+    key = _dev_key(dev)
     n = (lib.query('ds2_gru_sync_ws_bytes', bsz, hid) + 3) // 4
     if key not in _sync_ws or _sync_ws[key].numel() < n:
         _sync_ws[key] = torch.zeros(n, dtype=torch.int32, device=dev)
     return _sync_ws[key]
 
 
-def _use_persistent(bsz, hid):
+def _use_persistent(dev, bsz, hid):
     if GRU_MODE == 'step':
+        return False
+    if _dev_key(dev) in _persistent_off:
+        if GRU_MODE == 'persistent':
+            raise RuntimeError('persistent GRU kernels are disabled on %s: %s' % (dev, _persistent_off[_dev_key(dev)]))
         return False
     ok = bool(lib.query('ds2_gru_persistent_supported', bsz, hid))
     if GRU_MODE == 'persistent' and not ok:
-        raise RuntimeError('persistent GRU kernel does not support B=%d H=%d' % (bsz, hid))
+        raise RuntimeError('persistent GRU kernel does not support B=%d H=%d on this device' % (bsz, hid))
     return ok
 
 
+def _disable_persistent(dev, reason):
+    """Same process, later launches: this device uses the launch-per-step kernels from now on."""
+    import logging
+    _persistent_off[_dev_key(dev)] = reason
+    logging.getLogger('aes-lac-2018').warning('ds2hip: persistent GRU kernels disabled on %s (%s); using the '
+                                              'launch-per-step kernels', dev, reason)
+
+
 def async_error_words():
-    """Device views of the timeout flags of the persistent recurrence (one int32 per device workspace)."""
+    """Device views of the STICKY timeout flags of the persistent recurrence (one int32 per device workspace)."""
     word = lib.query('ds2_gru_sync_error_offset') // 4
     return [ws[word:word + 1] for ws in _sync_ws.values()]
 
 
 def raise_async_error():
-    for ws in _sync_ws.values():
+    """A bounded spin timed out somewhere since the last check: results of that step are invalid.  Reset the
+    workspaces (counters, flag), switch the affected devices to the per-step kernels for later launches, raise."""
+    for key, ws in _sync_ws.items():
+        word = lib.query('ds2_gru_sync_error_offset') // 4
+        bad = int(ws[word].item()) != 0
         ws.zero_()
-    raise RuntimeError('ds2hip: persistent GRU kernel timed out waiting for a workgroup hand-off')
+        if bad:
+            _disable_persistent(ws.device, 'a hand-off spin timed out (were all workgroups resident?)')
+    raise RuntimeError('ds2hip: persistent GRU kernel timed out waiting for a workgroup hand-off; the results of this '
+                       'step are invalid')
 
 
 def check_async_errors():
-    """Raise if a persistent kernel's bounded spin timed out (call after a device synchronize)."""
+    """Raise if a persistent kernel's bounded spin timed out since the last check (call after a device synchronize)."""
     for w in async_error_words():
         if int(w.item()) != 0:
             raise_async_error()
@@ -272,21 +297,31 @@ def gru_bidir_fwd(gates, w_hh, t, bsz, hid):
     """gates (T,B,2,3H) holds gi on entry, (r,z,n) on exit.  Returns (ghn (T,B,2,H), hout (2,T,B,H))."""
     ghn = _empty((t, bsz, 2, hid), gates)
     hout = _empty((2, t, bsz, hid), gates)
-    if _use_persistent(bsz, hid):
-        lib.call('ds2_gru_bidir_fwd_persistent', gates, ghn, hout, w_hh, _gru_sync_ws(gates.device, bsz, hid), t, bsz,
-                 hid)
-    else:
-        lib.call('ds2_gru_bidir_fwd', gates, ghn, hout, w_hh, t, bsz, hid)
+    if _use_persistent(gates.device, bsz, hid):
+        try:
+            lib.call('ds2_gru_bidir_fwd_persistent', gates, ghn, hout, w_hh, _gru_sync_ws(gates.device, bsz, hid), t,
+                     bsz, hid)
+            return ghn, hout
+        except lib.Ds2Error as e:               # nothing was launched: the chosen kernel's grid is not co-resident here
+            if e.code != lib.ERR_UNSUPPORTED or GRU_MODE == 'persistent':
+                raise
+            _disable_persistent(gates.device, str(e))
+    lib.call('ds2_gru_bidir_fwd', gates, ghn, hout, w_hh, t, bsz, hid)
     return ghn, hout
 
 
 def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid):
-    if _use_persistent(bsz, hid):
-        lib.call('ds2_gru_bidir_bwd_persistent', gates, ghn, hout, d_out, w_hh_t, _gru_sync_ws(gates.device, bsz, hid),
-                 t, bsz, hid)
-    else:
-        ws = torch.zeros((2 * 2 * bsz * hid,), dtype=torch.float32, device=gates.device)
-        lib.call('ds2_gru_bidir_bwd', gates, ghn, hout, d_out, w_hh_t, ws, t, bsz, hid)
+    if _use_persistent(gates.device, bsz, hid):
+        try:
+            lib.call('ds2_gru_bidir_bwd_persistent', gates, ghn, hout, d_out, w_hh_t,
+                     _gru_sync_ws(gates.device, bsz, hid), t, bsz, hid)
+            return
+        except lib.Ds2Error as e:
+            if e.code != lib.ERR_UNSUPPORTED or GRU_MODE == 'persistent':
+                raise
+            _disable_persistent(gates.device, str(e))
+    ws = torch.zeros((2 * 2 * bsz * hid,), dtype=torch.float32, device=gates.device)
+    lib.call('ds2_gru_bidir_bwd', gates, ghn, hout, d_out, w_hh_t, ws, t, bsz, hid)
 
 
 # ----------------------------------------------------------------------------- head / decode
@@ -312,14 +347,16 @@ def greedy_collapse(best, sizes, blank=0):
 
 
 # ----------------------------------------------------------------------------- CTC
-def ctc_loss_grad(acts, labels, label_offsets, label_lens, act_lens, max_label_len, grad_scale=1.0):
-    """acts (T,B,A) -> costs (B,), grad (T,B,A); int32 device tensors for the rest."""
+def ctc_loss_grad(acts, labels, label_offsets, label_lens, act_lens, max_label_len, grad_scale=1.0,
+                  zero_batch_if_inf=False):
+    """acts (T,B,A) -> costs (B,), grad (T,B,A); int32 device tensors for the rest.  ``zero_batch_if_inf``: the training
+    step's rule -- an infinite batch loss zeroes the whole batch's gradient (codes/engine.py:24-30)."""
     t, bsz, a = acts.shape
     costs = _empty((bsz,), acts)
     grad = torch.empty_like(acts)
     ws = _bytes_ws(lib.query('ds2_ctc_ws_bytes', t, bsz, a, max_label_len), acts)
     lib.call('ds2_ctc_loss_grad', acts, labels, label_offsets, label_lens, act_lens, t, bsz, a, max_label_len,
-             float(grad_scale), costs, grad, ws)
+             float(grad_scale), int(zero_batch_if_inf), costs, grad, ws)
     return costs, grad
 
 
@@ -329,6 +366,24 @@ def sumsq(x, out=None):
         out = torch.empty((1,), dtype=torch.float64, device=x.device)
     ws = _bytes_ws(lib.query('ds2_sumsq_ws_bytes', x.numel()), x)
     lib.call('ds2_sumsq', x, x.numel(), out, ws)
+    return out
+
+
+_err_ptr_tables = {}
+
+
+def step_stats(costs, sumsq_t, out=None):
+    """One launch gathering what the host reads after a step: [sum of costs, squared grad norm, any timeout flag,
+    number of infinite costs] as float64 (4,)."""
+    dev = costs.device
+    words = async_error_words()
+    key = (_dev_key(dev), tuple(w.data_ptr() for w in words))
+    table = _err_ptr_tables.get(key)
+    if table is None:
+        table = _err_ptr_tables[key] = torch.tensor([w.data_ptr() for w in words] or [0], dtype=torch.int64).to(dev)
+    if out is None:
+        out = torch.empty((4,), dtype=torch.float64, device=dev)
+    lib.call('ds2_step_stats', costs, costs.numel(), sumsq_t, table, len(words), out)
     return out
 
 

@@ -146,11 +146,18 @@ int ds2_transpose2d(const float* in, int rows, int cols, float* out, void* strea
  * one polling wave per consumer, write-through-coherent loads straight into MFMA operands.  The form
  * (4x4x1 or 16x16x4 MFMA, 1-3 batch parts) is chosen from B and H; results do not depend on it beyond
  * fp32 summation order.  Same arguments and results as the per-step calls; sync_ws is a caller-owned
- * device buffer of ds2_gru_sync_ws_bytes(B, H) bytes, 16-byte aligned (zeroed by the call).  Every
- * spin is bounded (5 s): on a timeout the 32-bit word at byte offset ds2_gru_sync_error_offset() of
- * sync_ws is set to 1 and the launch ends (results are then invalid -- check the word after
- * synchronising).  Returns DS2_ERR_UNSUPPORTED for shapes outside ds2_gru_persistent_supported(B, H)
- * (H % 16 == 0, 2*ceil(H/8) <= 240 co-resident workgroups, B <= 64). */
+ * device buffer of ds2_gru_sync_ws_bytes(B, H) bytes, 16-byte aligned, that the CALLER ZEROES ONCE
+ * when it allocates it: a launch that completes leaves its counters zero for the next one (the last
+ * workgroup to leave resets them), so no memset runs between launches.  Every spin is bounded (5 s):
+ * on a timeout the 32-bit word at byte offset ds2_gru_sync_error_offset() of sync_ws is set to 1 and
+ * the launch ends (results are then invalid).  The word is STICKY -- later launches never clear it --
+ * so one check after synchronising at the end of a step covers every launch of the step; after a
+ * reported timeout the caller zeroes the whole workspace before using it again.
+ * All workgroups of a launch must be resident at once: ds2_gru_persistent_supported(B, H) answers for
+ * the CURRENT device from its compute-unit count (grid <= 15/16 of the CUs, so a concurrent RCCL
+ * kernel keeps some) and the shape limits (H % 16 == 0, B <= 64); the launch itself re-checks the
+ * chosen kernel with hipOccupancyMaxActiveBlocksPerMultiprocessor.  DS2_ERR_UNSUPPORTED = use the
+ * per-step calls above instead (partitioned or smaller devices). */
 size_t ds2_gru_sync_ws_bytes(int B, int H);
 size_t ds2_gru_sync_error_offset(void);
 int ds2_gru_persistent_supported(int B, int H);
@@ -187,14 +194,17 @@ int ds2_ctc_beam_search(const float* probs, int T, int A, int blank, int beam_wi
  * grad = grad_scale * d(sum_b costs[b]) / d acts (zero for t >= act_lens[b]; zero for an utterance
  * whose alignment is infeasible, whose cost is +inf).  grad_scale carries the 1/B of
  * codes/engine.py:23,80 so no separate scaling pass is needed.
+ * zero_batch_if_inf = 1 adds the training step's rule (_sanitize_loss, codes/engine.py:24-30): when
+ * the batch loss is +-inf the reference replaces it by 0 * loss, so the WHOLE batch's gradient is
+ * zero (the optimizer step still runs, on momentum alone); 0 = warp-ctc's per-utterance contract.
  *   acts (T,B,A); labels flat int32 (sum label_lens); label_offsets (B) int32 start of each
  *   utterance's labels; ws >= ds2_ctc_ws_bytes(T,B,A,max_label_len) bytes
  */
 size_t ds2_ctc_ws_bytes(int T, int B, int A, int max_label_len);
 int ds2_ctc_loss_grad(const float* acts, const int32_t* labels, const int32_t* label_offsets,
                       const int32_t* label_lens, const int32_t* act_lens, int T, int B, int A,
-                      int max_label_len, float grad_scale, float* costs, float* grad, void* ws,
-                      void* stream);
+                      int max_label_len, float grad_scale, int zero_batch_if_inf, float* costs,
+                      float* grad, void* ws, void* stream);
 
 /* ------------------------------------------------------------------ optimiser
  * clip_grad_norm_(params, max_norm) + SGD(momentum, nesterov) (codes/engine.py:87-90) over ONE
@@ -210,6 +220,13 @@ int ds2_sumsq(const float* x, size_t n, double* out, void* ws, void* stream);
 int ds2_clip_sgd_nesterov(float* p, const float* g, float* buf, size_t n, const double* sumsq,
                           float grad_scale, float max_norm, float lr, float momentum, int first_step,
                           void* stream);
+
+/* Everything the host reads back after a training step (codes/engine.py:92-94: synchronize, loss.item()),
+ * gathered by ONE launch into out[0..3] (double): sum_b costs[b]; sumsq[0] (the squared gradient norm, or 0
+ * when sumsq is NULL); the OR of the n_err 32-bit words err_words[i] point at (device pointers held in a
+ * device array; the persistent recurrence's sticky timeout flags); the number of +-inf costs. */
+int ds2_step_stats(const float* costs, int B, const double* sumsq, const uint32_t* const* err_words, int n_err,
+                   double* out, void* stream);
 
 /* misc elementwise used by the layer glue */
 int ds2_add2(const float* a, const float* b, size_t n, float* out, void* stream);

@@ -141,6 +141,21 @@ def seeded_state_dict(model_or_shapes, seed, scale=None):
     return out
 
 
+def swap_fc_en_to_pt_br(linear_weight_en, seed, num_classes=43):
+    """The FC surgery of ``finetune_model`` (reference codes/utils/training_utils.py:96-120) as a pure function of the
+    old weight: rows listed in data/map_en-pt_BR.json are copied, the others come from N(0, 0.01) drawn with the
+    portable generator (the reference draws them with torch's global RNG)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = json.load(open(os.path.join(root, 'data', 'map_en-pt_BR.json')))
+    old_idx, new_idx = zip(*pairs)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w = (0.01 * rng.standard_normal((num_classes, linear_weight_en.shape[1]))).astype(np.float32)
+    w[list(new_idx)] = linear_weight_en[list(old_idx)]
+    return w
+
+
 def gru_direction_explicit(x, w_ih, w_hh, reverse=False):
     """One GRU direction written out (bias-free), returning every saved tensor.
 

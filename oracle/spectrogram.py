@@ -15,7 +15,7 @@ signal by reflect-padding n_fft//2 samples each side, cut frames of n_fft
 samples every hop, multiply by the window, real FFT.  Number of frames is
 1 + L // hop.  Parity with librosa itself is "unpinned"; the restatement is
 cross-checked against torch.stft(center=True, pad_mode='reflect') in
-tests/test_oracle_spectrogram.py.
+tests/test_oracle_misc.py.
 """
 import numpy as np
 

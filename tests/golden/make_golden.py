@@ -12,6 +12,17 @@ path, loads the portable weights-from-seed recipe (oracle/model.py
                  gradients of every parameter, BN running stats after the step.
   ref_full.npz   the default 5xBiGRU-800 model, B=2, T_in=301: train logits,
                  eval probs, loss, per-parameter gradient norms + strided samples.
+  ref_full_b8 / _b10 / _b32.npz
+                 the same model at the batch sizes of BASELINE configs[3] (8 per GPU),
+                 configs[1] (10) and configs[2] (32), ragged lengths.  To keep the
+                 fixtures small, logits / probs keep every ``tstride``-th output frame;
+                 the eval-mode argmax of EVERY frame is kept (uint8) so greedy strings
+                 are checked over the whole output.
+  ref_ft43_b16.npz
+                 the fine-tuned pt_BR head (A=43): the reference model's last Linear
+                 swapped as ``codes/utils/training_utils.py:87-122`` does -- rows of the
+                 en layer copied through data/map_en-pt_BR.json, the other rows from the
+                 seeded recipe -- then one forward/backward of the reference model.
 
 The GPU box regenerates weights and inputs from the same seeds, so only outputs
 are stored.  Nothing here is read at test time except the .npz files.
@@ -28,7 +39,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from oracle.model import seeded_state_dict  # noqa: E402
+from oracle.model import seeded_state_dict, swap_fc_en_to_pt_br  # noqa: E402
 
 
 def load_reference_model_module():
@@ -54,12 +65,31 @@ def seeded_labels(seed, label_lens, nalpha):
     return rng.integers(1, nalpha, size=int(sum(label_lens))).astype(np.int32)
 
 
-def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads):
+def ragged_lengths(seed, bsz, t_in, lo=0.35):
+    """Deterministic ragged frame counts: the first utterance full length (collate pads to the longest)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lens = sorted((int(v) for v in rng.integers(int(lo * t_in), t_in, size=bsz - 1)), reverse=True)
+    return [t_in] + lens
+
+
+def label_lengths_for(lengths, per_frame=0.09):
+    """Transcript lengths that stay feasible for CTC after the conv stack halves the frame rate."""
+    return [max(1, int(per_frame * n)) for n in lengths]
+
+
+def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads, tstride=1, finetune43=False):
     torch.manual_seed(0)
     model = ref.DeepSpeech(**model_kwargs)
     sd = seeded_state_dict(model, seed=1234)
     model.load_state_dict(sd)
     nalpha = model_kwargs.get('num_classes', 29)
+    if finetune43:
+        old = model.fc[0].module[1]
+        new = torch.nn.Linear(old.in_features, 43, bias=False)       # training_utils.py:100-104
+        with torch.no_grad():
+            new.weight.copy_(torch.from_numpy(swap_fc_en_to_pt_br(old.weight.detach().numpy(), seed=4343)))
+        model.fc[0].module[1] = new
+        nalpha = 43
     x = torch.from_numpy(seeded_inputs(77, bsz, t_in, lengths=lengths))
     labels = seeded_labels(78, label_lens, nalpha)
     out = {}
@@ -86,7 +116,8 @@ def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads
     model.zero_grad()
     total.backward()
 
-    out['logits'] = logits.detach().numpy()
+    out['logits'] = logits.detach().numpy()[:, ::tstride].copy()
+    out['tstride'] = np.int32(tstride)
     out['loss_sum'] = np.float32(loss.item())
     out['out_sizes'] = out_sizes.numpy().astype(np.int32)
     out['pct'] = pct.numpy()
@@ -109,18 +140,45 @@ def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads
     model.eval()
     with torch.no_grad():
         probs = model(x)
-    out['probs'] = probs.numpy()
+    out['probs'] = probs.numpy()[:, ::tstride].copy()
+    if tstride > 1:
+        # every frame: best and runner-up class plus whether they are closer than 1e-4 (with near-uniform outputs of
+        # random weights some frames are ties at fp32 round-off; there the runner-up is an equally valid argmax)
+        order = np.argsort(-probs.numpy(), axis=-1, kind='stable')
+        top = np.take_along_axis(probs.numpy(), order[..., :2], -1)
+        out['argmax'] = order[..., 0].astype(np.uint8)
+        out['argmax2'] = order[..., 1].astype(np.uint8)
+        out['near_tie'] = ((top[..., 0] - top[..., 1]) < 1e-4)
     np.savez_compressed(os.path.join(HERE, name), **out)
     print(name, 'logits', out['logits'].shape, 'loss', out['loss_sum'],
           'size %.1f KB' % (os.path.getsize(os.path.join(HERE, name)) / 1024.0))
 
 
+def cases():
+    yield 'ref_tiny.npz', dict(model_kwargs=dict(rnn_hidden_size=32, num_rnn_layers=2, num_classes=29), bsz=3, t_in=121,
+                               lengths=[121, 97, 64], label_lens=[9, 6, 4], full_grads=True)
+    yield 'ref_full.npz', dict(model_kwargs=dict(), bsz=2, t_in=301, lengths=[301, 233], label_lens=[30, 21],
+                               full_grads=False)
+    for bsz, t_in, tstride in ((8, 301, 2), (10, 301, 2), (32, 301, 6)):
+        lens = ragged_lengths(500 + bsz, bsz, t_in)
+        yield 'ref_full_b%d.npz' % bsz, dict(model_kwargs=dict(), bsz=bsz, t_in=t_in, lengths=lens,
+                                             label_lens=label_lengths_for(lens), full_grads=False, tstride=tstride)
+    lens = ragged_lengths(516, 16, 261)
+    yield 'ref_ft43_b16.npz', dict(model_kwargs=dict(), bsz=16, t_in=261, lengths=lens,
+                                   label_lens=label_lengths_for(lens), full_grads=False, tstride=4, finetune43=True)
+
+
+CASES = dict(cases())
+
+
 def main():
+    """``make_golden.py`` regenerates everything; ``make_golden.py ref_full_b8.npz ...`` only the named fixtures."""
     ref = load_reference_model_module()
-    run_case(ref, 'ref_tiny.npz', dict(rnn_hidden_size=32, num_rnn_layers=2, num_classes=29),
-             bsz=3, t_in=121, lengths=[121, 97, 64], label_lens=[9, 6, 4], full_grads=True)
-    run_case(ref, 'ref_full.npz', dict(), bsz=2, t_in=301, lengths=[301, 233], label_lens=[30, 21],
-             full_grads=False)
+    for name, kw in CASES.items():
+        if sys.argv[1:] and name not in sys.argv[1:]:
+            continue
+        kw = dict(kw)
+        run_case(ref, name, kw.pop('model_kwargs'), **kw)
 
 
 if __name__ == '__main__':

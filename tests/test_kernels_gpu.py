@@ -1,4 +1,6 @@
 """Per-kernel parity of the HIP path (through the C ABI) against the CPU oracle.  Needs an MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -217,7 +219,8 @@ def test_bn1d_with_direction_sum(ops):
 # ------------------------------------------------------------------------------------------- GRU
 @pytest.mark.parametrize('mode', ['step', 'persistent'])
 @pytest.mark.parametrize('t,bsz,n_in,hid', [(9, 3, 24, 32), (6, 10, 40, 800), (5, 20, 16, 64), (4, 40, 16, 72),
-                                            (3, 64, 8, 800), (1, 2, 8, 16), (40, 33, 8, 256), (25, 17, 8, 512)])
+                                            (3, 64, 8, 800), (1, 2, 8, 16), (40, 33, 8, 256), (25, 17, 8, 512),
+                                            (7, 8, 16, 800), (5, 32, 16, 800), (6, 16, 16, 800)])
 def test_gru_recurrence_fwd_bwd(ops, monkeypatch, mode, t, bsz, n_in, hid):
     if mode == 'persistent' and hid % 16 != 0:
         pytest.skip('persistent kernel needs H % 16 == 0 (falls back to the per-step kernels)')
@@ -265,7 +268,7 @@ def test_gru_recurrence_fwd_bwd(ops, monkeypatch, mode, t, bsz, n_in, hid):
 
 
 @pytest.mark.parametrize('fwd_form,bwd_form', [('4', '4'), ('16', '16'), ('4', '16'), ('16', '4')])
-@pytest.mark.parametrize('t,bsz,hid', [(7, 10, 800), (5, 27, 256), (4, 32, 800), (6, 5, 64)])
+@pytest.mark.parametrize('t,bsz,hid', [(7, 10, 800), (5, 27, 256), (4, 32, 800), (6, 5, 64), (9, 8, 800)])
 def test_gru_persistent_mfma_forms_agree_with_step_kernels(ops, monkeypatch, fwd_form, bwd_form, t, bsz, hid):
     """Both MFMA forms of each persistent kernel (4x4x1 and 16x16x4; the default depends on the batch size) against
     the launch-per-step kernels on the same inputs."""
@@ -354,6 +357,12 @@ def test_ctc_infeasible_and_long(ops):
     np.testing.assert_allclose(costs.cpu().numpy()[0], rc[0], rtol=1e-5)
     assert np.all(grad.cpu().numpy()[:, 1] == 0)
     np.testing.assert_allclose(grad.cpu().numpy()[:, 0], rg[:, 0], atol=2e-5)
+    # the training step's rule (codes/engine.py:24-30): one infinite cost zeroes the WHOLE batch's gradient
+    costs2, grad2 = ops.ctc_loss_grad(_t(acts), _t(labels), _t(np.asarray([0, 2], np.int32)),
+                                      _t(np.asarray([2, 3], np.int32)), _t(np.asarray([8, 4], np.int32)), 3,
+                                      zero_batch_if_inf=True)
+    assert np.array_equal(costs2.cpu().numpy(), costs.cpu().numpy())
+    assert np.all(grad2.cpu().numpy() == 0)
     # long utterance: T = 746, L = 200 (S = 401 states, two states per thread)
     costs, grad, rc, rg = _ctc_case(ops, 746, 2, 29, [200, 150], [746, 700], seed=9)
     np.testing.assert_allclose(costs, rc, rtol=1e-4)
@@ -381,35 +390,34 @@ def test_clip_sgd_matches_torch(ops):
         np.testing.assert_allclose(pd[:n].cpu().numpy(), p.detach().numpy(), atol=2e-6)
 
 
-def test_gru_persistent_lost_arrival_times_out_instead_of_hanging(ops, monkeypatch):
-    """Every spin in the persistent kernels is bounded: with one workgroup's arrival suppressed (DS2_GRU_DBG = 64) the
-    launch ends after the 5 s timeout, the host sees the flag and raises, and the next launch works again."""
-    import time
-    t, bsz, hid = 6, 10, 800
-    torch.manual_seed(0)
+@pytest.mark.parametrize('which', ['fwd', 'bwd'])
+def test_gru_persistent_lost_arrival_times_out_instead_of_hanging(which):
+    """Every spin in the persistent kernels is bounded: with one workgroup's arrival suppressed the launch ends after
+    the 5 s timeout, the STICKY flag survives later launches until the host checks it, the device falls back to the
+    per-step kernels for later launches, and after the host's reset the persistent kernels work again.  Runs against
+    the fault-injection build in a fresh process (tests/fault_inject_worker.py); the release library has no such hook."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'fault_inject_worker.py'), which],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, DS2_GRU_MODE='auto'))
+    assert out.returncode == 0 and 'OK ' + which in out.stdout, out.stderr[-3000:]
+
+
+def test_release_library_ignores_the_debug_variable(ops, monkeypatch):
+    """DS2_GRU_DBG must not change results of the shipped library (it used to skip waits / MFMAs / arrivals)."""
+    t, bsz, hid = 5, 10, 800
+    torch.manual_seed(1)
     w_hh = (torch.randn(2, 3 * hid, hid) * 0.02).to(DEV)
-    w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
     gi = torch.randn(t, bsz, 2, 3 * hid).to(DEV)
-    d_out = torch.randn(t, bsz, hid).to(DEV)
     monkeypatch.setattr(ops, 'GRU_MODE', 'persistent')
-    g = gi.clone()
-    ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
-    good = (g.clone(), ghn.clone(), hout.clone())
-    for which in ('fwd', 'bwd'):
-        monkeypatch.setenv('DS2_GRU_DBG', '64')
-        t0 = time.time()
-        if which == 'fwd':
-            ops.gru_bidir_fwd(gi.clone(), w_hh, t, bsz, hid)
-        else:
-            ops.gru_bidir_bwd(g.clone(), ghn.clone(), hout, d_out, w_hh_t, t, bsz, hid)
-        torch.cuda.synchronize()
-        assert 3.0 < time.time() - t0 < 60.0
-        with pytest.raises(RuntimeError, match='timed out'):
-            ops.check_async_errors()
-        monkeypatch.setenv('DS2_GRU_DBG', '0')
-        g2 = gi.clone()
-        ghn2, hout2 = ops.gru_bidir_fwd(g2, w_hh, t, bsz, hid)
+    res = []
+    for dbg in ('0', '67'):
+        monkeypatch.setenv('DS2_GRU_DBG', dbg)
+        g = gi.clone()
+        ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
         torch.cuda.synchronize()
         ops.check_async_errors()
-        for a, b in zip((g2, ghn2, hout2), good):
-            assert torch.equal(a, b) or float((a - b).abs().max()) < 1e-6
+        res.append((g, ghn, hout))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

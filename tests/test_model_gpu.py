@@ -297,3 +297,52 @@ def test_fused_step_with_param_groups_and_frozen_conv():
         assert abs(got - float(loss.item())) <= 2e-4 * abs(float(loss.item()))
         for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
             np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), atol=5e-5, err_msg='%s step %d' % (k, step))
+
+
+@pytest.mark.parametrize('optimizer', ['sgd_fused', 'sgd_autograd'])
+def test_infinite_batch_loss_is_a_zero_gradient_step_on_both_paths(optimizer, caplog):
+    """``_sanitize_loss`` (codes/engine.py:24-30) turns an infinite batch loss into ``0 * loss``: the reported value is 0,
+    no utterance contributes a gradient, and ``optimizer.step()`` still runs (momentum moves the weights).  The fused
+    step and the autograd step must both do exactly that -- equal to torch SGD stepping on all-zero gradients."""
+    from codes.ctc import CTCLoss
+    from codes.engine import Trainer
+    kwargs = dict(rnn_hidden_size=32, num_rnn_layers=2, num_classes=29)
+    oracle = OracleDeepSpeech(**kwargs)
+    oracle.load_state_dict(seeded_state_dict(oracle, 77))
+    model = _build(kwargs)
+    model.load_state_dict(seeded_state_dict(oracle, 77))
+    model.to('cuda')
+    opt_o = torch.optim.SGD(oracle.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
+    if optimizer == 'sgd_fused':
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
+    else:            # weight_decay=0 but dampening set: not the fused kernel's form -> the reference-shaped autograd step
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, dampening=0.0, nesterov=True, weight_decay=1e-30)
+    trainer = Trainer(model, opt, CTCLoss(), device='cuda', max_norm=400)
+    assert trainer._fused == (optimizer == 'sgd_fused')
+    x = torch.from_numpy(seeded_inputs(5, 3, 80))
+    pct = torch.ones(3)
+    ok_labels = (torch.tensor([1, 2, 3, 4, 5, 6], dtype=torch.int32), torch.tensor([3, 2, 1], dtype=torch.int32))
+    # utterance 1 asks for 40 labels out of 35 output frames: infeasible, cost +inf
+    bad_labels = (torch.tensor([1, 2] + [3] * 40 + [4], dtype=torch.int32), torch.tensor([2, 40, 1], dtype=torch.int32))
+    for step, (labels, sizes) in enumerate((ok_labels, bad_labels, ok_labels)):
+        oracle.train()
+        logits = oracle(x)
+        out_sizes = (pct * logits.shape[1]).int()
+        loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), labels.long(), out_sizes.long(), sizes.long(), blank=0,
+                          reduction='sum') / 3
+        opt_o.zero_grad()
+        if torch.isinf(loss):
+            for p in oracle.parameters():
+                p.grad = torch.zeros_like(p)                 # 0 * loss: zero gradients, the step still runs
+            want = 0.0
+        else:
+            loss.backward()
+            want = float(loss.item())
+        torch.nn.utils.clip_grad_norm_(oracle.parameters(), 400)
+        opt_o.step()
+        got = trainer.update((x, labels, pct, sizes))
+        assert abs(got - want) <= 2e-4 * max(abs(want), 1.0), (step, got, want)
+        if step == 1:
+            assert got == 0.0 and 'received an inf loss' in caplog.text
+        for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), atol=5e-5, err_msg='%s step %d' % (k, step))

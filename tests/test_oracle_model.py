@@ -67,3 +67,41 @@ def test_explicit_gru_equals_nn_gru():
     r = gru_direction_explicit(x, gru.weight_ih_l0_reverse, gru.weight_hh_l0_reverse, reverse=True)
     np.testing.assert_allclose(f['h'].detach().numpy(), y[:, :, :h].detach().numpy(), atol=1e-6)
     np.testing.assert_allclose(r['h'].detach().numpy(), y[:, :, h:].detach().numpy(), atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# full-size fixtures at the batch sizes of BASELINE configs[1..4] (tests/golden_cases.py)
+def _oracle_case(golden_dir, name):
+    import pytest  # noqa: F401
+    from oracle.model import swap_fc_en_to_pt_br
+    from tests.golden_cases import FT43_SEED, case_inputs, check_against_golden
+    g = np.load(os.path.join(golden_dir, name))
+    kw, x, labels, nalpha = case_inputs(name)
+    model = OracleDeepSpeech()
+    model.load_state_dict(seeded_state_dict(model, 1234))
+    if kw.get('finetune43'):
+        head = model.fc[0].module
+        new = torch.nn.Linear(800, 43, bias=False)
+        with torch.no_grad():
+            new.weight.copy_(torch.from_numpy(swap_fc_en_to_pt_br(head[1].weight.detach().numpy(), FT43_SEED)))
+        head[1] = new
+    model.train()
+    logits = model(torch.from_numpy(x))
+    loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), torch.from_numpy(labels).long(),
+                      torch.from_numpy(g['out_sizes']).long(), torch.tensor(kw['label_lens']), blank=0, reduction='sum')
+    (loss / kw['bsz']).backward()
+    grads = {k: p.grad.numpy() for k, p in model.named_parameters()}
+    bufs = {k: v.numpy().copy() for k, v in model.state_dict().items() if 'running' in k}
+    model.eval()
+    with torch.no_grad():
+        probs = model(torch.from_numpy(x))
+    check_against_golden(g, logits.detach().numpy(), float(loss.item()), grads, bufs, probs.numpy(), logit_tol=2e-5,
+                         prob_tol=1e-5, gnorm_rtol=1e-4, gsample_rtol=1e-3, buf_rtol=1e-5, buf_atol=1e-6)
+
+
+def test_full_model_b8_matches_reference(golden_dir):
+    _oracle_case(golden_dir, 'ref_full_b8.npz')
+
+
+def test_finetuned_pt_br_head_matches_reference(golden_dir):
+    _oracle_case(golden_dir, 'ref_ft43_b16.npz')
