@@ -77,7 +77,8 @@ def label_lengths_for(lengths, per_frame=0.09):
     return [max(1, int(per_frame * n)) for n in lengths]
 
 
-def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads, tstride=1, finetune43=False):
+def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads, tstride=1, finetune43=False,
+             f64_truth=False):
     torch.manual_seed(0)
     model = ref.DeepSpeech(**model_kwargs)
     sd = seeded_state_dict(model, seed=1234)
@@ -136,6 +137,24 @@ def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads
     for k, v in model.state_dict().items():
         if 'running' in k:
             out['buf_' + k] = v.numpy().copy()
+    if f64_truth:
+        # The same step of the reference model in float64: how far the reference's OWN fp32 gradients are from the exact
+        # ones (conv2's filter gradient sums ~10^5 products per element: 2.4e-3 of the largest element at B = 32).  The
+        # parity tests allow the HIP path that much distance from the fp32 reference, no more.
+        model64 = ref.DeepSpeech(**model_kwargs)
+        model64.load_state_dict(sd)
+        if finetune43:
+            model64.fc[0].module[1] = torch.nn.Linear(model.fc[0].module[1].in_features, 43, bias=False)
+            model64.fc[0].module[1].load_state_dict(model.fc[0].module[1].state_dict())
+        model64 = model64.double().train()
+        logits64 = model64(x.double())
+        loss64 = F.ctc_loss(logits64.transpose(0, 1).log_softmax(-1), torch.from_numpy(labels).long(), out_sizes.long(),
+                            torch.tensor(label_lens, dtype=torch.long), blank=0, reduction='sum')
+        (loss64 / bsz).backward()
+        for k, p in model64.named_parameters():
+            flat = p.grad.numpy().reshape(-1)
+            stride = max(1, flat.shape[0] // 1024)
+            out['gnoise_' + k] = np.float32(np.abs(flat[::stride][:1024] - out['gsample_' + k]).max())
 
     model.eval()
     with torch.no_grad():
@@ -162,10 +181,12 @@ def cases():
     for bsz, t_in, tstride in ((8, 301, 2), (10, 301, 2), (32, 301, 6)):
         lens = ragged_lengths(500 + bsz, bsz, t_in)
         yield 'ref_full_b%d.npz' % bsz, dict(model_kwargs=dict(), bsz=bsz, t_in=t_in, lengths=lens,
-                                             label_lens=label_lengths_for(lens), full_grads=False, tstride=tstride)
+                                             label_lens=label_lengths_for(lens), full_grads=False, tstride=tstride,
+                                             f64_truth=True)
     lens = ragged_lengths(516, 16, 261)
     yield 'ref_ft43_b16.npz', dict(model_kwargs=dict(), bsz=16, t_in=261, lengths=lens,
-                                   label_lens=label_lengths_for(lens), full_grads=False, tstride=4, finetune43=True)
+                                   label_lens=label_lengths_for(lens), full_grads=False, tstride=4, finetune43=True,
+                                   f64_truth=True)
 
 
 CASES = dict(cases())

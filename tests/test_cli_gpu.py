@@ -50,6 +50,14 @@ def test_train_then_test_cli(tmp_path):
     assert ckpt.exists()
     payload = torch.load(str(ckpt), map_location='cpu', weights_only=False)
     assert payload['epoch'] == 2 and 'rnns.1.batch_norm.module.running_mean' in payload['state_dict']
+    # epoch-end behaviour of the reference (train.py:272-374): train + val metric histories, metrics-log, best-CER files
+    assert payload['iteration'] == 4
+    for hist in (payload['metrics'], payload['val_metrics']):
+        assert sorted(hist) == ['cer', 'ctcloss', 'wer'] and all(len(v) == 2 for v in hist.values())
+    lines = (tmp_path / 'results' / 'tiny' / 'metrics-log').read_text().splitlines()
+    assert len(lines) == 2 and lines[1].startswith('Epoch [2] | Train ctcloss ') and '| Val ctcloss ' in lines[1]
+    assert (tmp_path / 'results' / 'tiny' / 'model_best-ckpt_1.pth').exists()
+    assert 'Training Summary Epoch: [1]' in log and 'Annealing learning rate' in log
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'test.py'), '--model-path', str(ckpt), '--data-dir',
                           str(tmp_path), '--manifest', str(tmp_path / 'val.csv'), '--batch-size', '2', '--num-workers',
                           '0', '--cuda'], capture_output=True, text=True, env=env, timeout=600)
@@ -61,6 +69,31 @@ def test_train_then_test_cli(tmp_path):
                          timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert 'Test Summary' in out.stdout and 'Average CER' in out.stdout
+
+
+def test_resume_from_a_mid_epoch_checkpoint(tmp_path):
+    """--checkpoint-per-batch + --continue-from (train.py:127-157,389-399): the resumed run skips the batches the
+    checkpoint already covers, counts iterations once, starts from shuffled bins, and appends to the histories."""
+    _corpus(tmp_path)
+    base = [sys.executable, os.path.join(ROOT, 'train.py'), str(tmp_path / 'tiny.json'), '--data-dir', str(tmp_path),
+            '--train-manifest', str(tmp_path / 'train.csv'), '--val-manifest', str(tmp_path / 'val.csv'), '--local',
+            '--num-workers', '0', '--save-folder', str(tmp_path / 'results')]
+    out = subprocess.run(base + ['--checkpoint-per-batch', '1'], capture_output=True, text=True, env=dict(os.environ),
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    mid = tmp_path / 'results' / 'tiny' / 'model_batch-ckpt_3.pth'           # epoch 2 (of 2), one of its two batches done
+    payload = torch.load(str(mid), map_location='cpu', weights_only=False)
+    assert payload['epoch'] == 1 and payload['iteration'] == 3 and len(payload['val_metrics']['cer']) == 1
+    out = subprocess.run(base + ['--continue-from', str(mid), '--checkpoint', '--save-folder',
+                                 str(tmp_path / 'resumed')], capture_output=True, text=True, env=dict(os.environ),
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    log = out.stderr + out.stdout
+    assert 'Start epoch: 1. Start iteration 3' in log and 'Shuffling batches for the following epochs' in log
+    assert 'Epoch: [2][2/2]' in log and 'Epoch: [2][1/2]' not in log and 'Epoch: [1][' not in log
+    final = torch.load(str(tmp_path / 'resumed' / 'tiny' / 'model_ckpt_2.pth'), map_location='cpu', weights_only=False)
+    assert final['epoch'] == 2 and final['iteration'] == 4
+    assert len(final['val_metrics']['cer']) == 2 and final['val_metrics']['cer'][0] == payload['val_metrics']['cer'][0]
 
 
 def test_train_cli_distributed_launch(tmp_path):

@@ -312,3 +312,23 @@ def test_tempo_and_gain_augmentation(tmp_path):
     np.random.seed(5)
     assert torch.equal(ToTensor(augment=True)(path), aug)                      # reproducible from the seed
     assert 'augment=True' in repr(ToTensor(augment=True))
+
+
+def test_metrics_log_format_and_best_checkpoints(tmp_path):
+    """train.py's epoch-end files: the reference's metrics-log record (train.py:359-374) and the five best-CER
+    checkpoints (train.py:223-229, lowest CER kept)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ds2_train_cli', os.path.join(ROOT, 'train.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    log = tmp_path / 'metrics-log'
+    train_h, val_h = {'ctcloss': [3.0], 'wer': [90.0], 'cer': [50.0]}, {'ctcloss': [4.0], 'wer': [(95.0, 96.5)], 'cer': [60]}
+    cli.write_metrics_log(str(log), 1, train_h, val_h)
+    assert log.read_text() == 'Epoch [1] | Train ctcloss 3.000wer 90.000cer 50.000| Val ctcloss 4.000wer 95.000/96.500cer 60\n'
+    best = cli.BestCheckpoints(str(tmp_path), n_saved=2)
+    for cer in (30.0, 10.0, 20.0, 40.0, 5.0):
+        best(cer, {'cer': cer})
+    kept = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('model_best-ckpt_'))
+    assert kept == ['model_best-ckpt_2.pth', 'model_best-ckpt_5.pth']          # CER 10 and 5
+    args = cli.build_parser().parse_args(['cfg.json', '--train-manifest', 'a', '--val-manifest', 'b', '--no-sorta-grad'])
+    assert args.no_sorta_grad and not args.no_shuffle

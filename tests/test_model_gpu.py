@@ -315,9 +315,9 @@ def test_infinite_batch_loss_is_a_zero_gradient_step_on_both_paths(optimizer, ca
     opt_o = torch.optim.SGD(oracle.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
     if optimizer == 'sgd_fused':
         opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, nesterov=True)
-    else:            # weight_decay=0 but dampening set: not the fused kernel's form -> the reference-shaped autograd step
+    else:            # a (negligible) weight decay is not the fused kernel's form -> the reference-shaped autograd step
         opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9, dampening=0.0, nesterov=True, weight_decay=1e-30)
-    trainer = Trainer(model, opt, CTCLoss(), device='cuda', max_norm=400)
+    trainer = Trainer(model, opt, CTCLoss(), device='cuda', max_norm=5.0)    # (clipped steps keep fp32 noise x lr small)
     assert trainer._fused == (optimizer == 'sgd_fused')
     x = torch.from_numpy(seeded_inputs(5, 3, 80))
     pct = torch.ones(3)
@@ -338,7 +338,7 @@ def test_infinite_batch_loss_is_a_zero_gradient_step_on_both_paths(optimizer, ca
         else:
             loss.backward()
             want = float(loss.item())
-        torch.nn.utils.clip_grad_norm_(oracle.parameters(), 400)
+        torch.nn.utils.clip_grad_norm_(oracle.parameters(), 5.0)
         opt_o.step()
         got = trainer.update((x, labels, pct, sizes))
         assert abs(got - want) <= 2e-4 * max(abs(want), 1.0), (step, got, want)
