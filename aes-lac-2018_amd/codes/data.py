@@ -26,8 +26,12 @@ def collate(batch):
 
 
 def collate_audio(batch):
-    """batch: list of (wav 1-D tensor, labels) -> (wavs list, targets, target_sizes) for the GPU frontend."""
+    """batch: list of (wav, labels) -> (wavs, targets, target_sizes) for the GPU frontend.  ``wav`` is a 1-D float tensor
+    (then ``wavs`` is the list of them) or a ``PCMClip`` of int16 samples (then ``wavs`` is ONE ``RawAudioBatch``)."""
+    from .transforms import PCMClip, RawAudioBatch
     wavs = [b[0] for b in batch]
+    if wavs and isinstance(wavs[0], PCMClip):
+        wavs = RawAudioBatch.from_clips(wavs)
     flat = [int(v) for b in batch for v in b[1]]
     sizes = torch.tensor([len(b[1]) for b in batch], dtype=torch.int)
     return wavs, torch.tensor(flat, dtype=torch.int), sizes
@@ -82,3 +86,44 @@ def _collate_spect(batch):
 def _collate_raw(batch):
     wavs, targets, sizes = collate_audio([(w, _labels_list(t)) for w, t in batch])
     return wavs, targets, None, sizes
+
+
+class DevicePrefetcher(object):
+    """Iterate a loader of ``(RawAudioBatch, targets, None, sizes)`` one minibatch AHEAD: while the GPU works on step i
+    the int16 samples of step i+1 cross PCIe on a copy stream (from page-locked memory when the loader pins), so the
+    training step never waits for an upload.  The consumer (``BatchSpectrogram``) waits on the batch's ``ready`` event
+    on its own stream.  Batches that are not ``RawAudioBatch`` pass through unchanged."""
+
+    def __init__(self, loader, device='cuda'):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    @property
+    def batch_sampler(self):
+        return self.loader.batch_sampler
+
+    def _stage(self, batch):
+        from .transforms import RawAudioBatch
+        wavs = batch[0]
+        if not isinstance(wavs, RawAudioBatch):
+            return batch
+        with torch.cuda.stream(self.stream):
+            dev = wavs.to(self.device, non_blocking=True)
+            dev.ready = torch.cuda.Event()
+            dev.ready.record(self.stream)
+            dev._host = wavs                         # keep the page-locked source alive until the copy has run
+        return (dev,) + tuple(batch[1:])
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        for batch in it:
+            cur, nxt = nxt, self._stage(batch)
+            yield cur
+        yield nxt

@@ -126,7 +126,7 @@ class Trainer(object):
             model.train()
         t0 = time.time()
         inputs, targets, input_percentages, target_sizes = batch
-        if self.frontend is not None and isinstance(inputs, (list, tuple)):
+        if self.frontend is not None and not isinstance(inputs, torch.Tensor):   # list of clips or a RawAudioBatch
             inputs, input_percentages = self.frontend(inputs)          # raw clips -> device spectrograms
         inputs = inputs.to(self.device, non_blocking=True)
         self.data_time = time.time() - t0

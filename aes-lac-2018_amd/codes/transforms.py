@@ -62,7 +62,14 @@ class BatchSpectrogram(object):
         self.normalize, self.eps, self.device = normalize, eps, device
 
     def __call__(self, wavs, offsets=None):
-        if offsets is None:
+        if isinstance(wavs, RawAudioBatch):                  # int16 clips (+ drawn augmentation): decode on the device
+            if wavs.ready is not None:               # uploaded ahead of time on the prefetcher's copy stream
+                torch.cuda.current_stream().wait_event(wavs.ready)
+                wavs.pcm.record_stream(torch.cuda.current_stream())
+            pcm = wavs.pcm if wavs.pcm.is_cuda else wavs.pcm.to(self.device, non_blocking=True)
+            flat, offs = ops.decode_augment(pcm, wavs.offsets, wavs.tempos, wavs.gains_db)
+            lens = [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
+        elif offsets is None:
             lens = [int(w.numel()) for w in wavs]
             flat = torch.cat([w.reshape(-1).to(self.device, torch.float32) for w in wavs])
         else:
@@ -80,7 +87,8 @@ class BatchSpectrogram(object):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# Host-side neighbours of the hot path: waveform loading and transcript -> labels.
+# Neighbours of the hot path: waveform loading (+ augmentation, on the device) and
+# transcript -> labels (host).
 # ---------------------------------------------------------------------------------------------------------
 class Compose(object):
     def __init__(self, transforms):
@@ -92,58 +100,67 @@ class Compose(object):
         return x
 
 
-def wsola_tempo(x, tempo, sample_rate=16000, segment_ms=82.0, search_ms=14.68, overlap_ms=12.0):
-    """Change the tempo of a 1-D float array without changing its pitch (WSOLA: waveform-similarity overlap-add).
+class PCMClip(object):
+    """What a loader worker hands on for one utterance: the int16 samples as read from the file plus the augmentation
+    DRAWN for it (tempo factor, gain in dB; None = no augmentation).  The arithmetic -- int16 -> float, WSOLA tempo,
+    gain, 16-bit requantisation -- happens on the GPU after collate (``ds2hip.ops.decode_augment``)."""
+    __slots__ = ('pcm', 'tempo', 'gain_db')
 
-    Stands in for ``sox ... tempo <factor>`` (``codes/transforms.py:185-218``), whose defaults are a 82 ms segment,
-    a 14.68 ms search window and a 12 ms overlap.  Output length ~ len(x) / tempo.  The segment that continues the
-    output is looked for around the ideal input position, where it correlates best with the natural continuation of
-    the previous segment, and cross-faded in over the overlap.  Not bit-compatible with sox (nor claimed to be)."""
-    import numpy as np
-    x = np.asarray(x, dtype=np.float32).reshape(-1)
-    if abs(tempo - 1.0) < 1e-6 or x.size == 0:
-        return x.copy()
-    seg = max(int(sample_rate * segment_ms / 1000.0), 4)
-    ovl = max(min(int(sample_rate * overlap_ms / 1000.0), seg // 2), 1)
-    half = max(int(sample_rate * search_ms / 1000.0) // 2, 1)
-    hop_out = seg - ovl
-    hop_in = tempo * hop_out
-    if x.size <= seg + half:
-        return x.copy()
-    fade_in = np.linspace(0.0, 1.0, ovl, endpoint=False, dtype=np.float32)
-    out = np.zeros(int(x.size / tempo) + 2 * seg, dtype=np.float32)
-    out[:seg] = x[:seg]
-    out_pos, prev, ideal = hop_out, 0, 0.0
-    while True:
-        ideal += hop_in
-        base = int(round(ideal))
-        lo, hi = max(base - half, 0), min(base + half, x.size - seg)
-        if hi < lo:
-            break
-        want = x[prev + hop_out: prev + hop_out + ovl]                # how the previous segment would have gone on
-        if want.size < ovl:
-            break
-        window = x[lo: hi + ovl]
-        corr = np.correlate(window, want, mode='valid')                # corr[d] = <x[lo + d : lo + d + ovl], want>
-        start = lo + int(np.argmax(corr))
-        out[out_pos: out_pos + ovl] = out[out_pos: out_pos + ovl] * (1.0 - fade_in) + x[start: start + ovl] * fade_in
-        out[out_pos + ovl: out_pos + seg] = x[start + ovl: start + seg]
-        prev, out_pos = start, out_pos + hop_out
-    return out[: out_pos + ovl]
+    def __init__(self, pcm, tempo=None, gain_db=None):
+        self.pcm, self.tempo, self.gain_db = pcm, tempo, gain_db
+
+    def numel(self):
+        return int(self.pcm.numel())
+
+
+class RawAudioBatch(object):
+    """A collated minibatch of ``PCMClip``s: ONE int16 buffer (page-locked when the DataLoader pins) + clip offsets +
+    the per-clip augmentation parameters.  2 bytes per sample cross PCIe; everything else happens on the device."""
+
+    def __init__(self, pcm, offsets, tempos=None, gains_db=None):
+        self.pcm, self.offsets, self.tempos, self.gains_db = pcm, list(offsets), tempos, gains_db
+        self.ready = None                            # event recorded behind an asynchronous upload (DevicePrefetcher)
+
+    @classmethod
+    def from_clips(cls, clips):
+        offs = [0]
+        for c in clips:
+            offs.append(offs[-1] + c.numel())
+        pcm = torch.cat([c.pcm.reshape(-1) for c in clips]) if clips else torch.zeros(0, dtype=torch.int16)
+        aug = any(c.tempo is not None or c.gain_db is not None for c in clips)
+        tempos = [1.0 if c.tempo is None else float(c.tempo) for c in clips] if aug else None
+        gains = [0.0 if c.gain_db is None else float(c.gain_db) for c in clips] if aug else None
+        return cls(pcm, offs, tempos, gains)
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def pin_memory(self):                            # torch DataLoader(pin_memory=True) calls this on custom batch types
+        self.pcm = self.pcm.pin_memory()
+        return self
+
+    def to(self, device, non_blocking=False):
+        out = RawAudioBatch(self.pcm.to(device, non_blocking=non_blocking), self.offsets, self.tempos, self.gains_db)
+        return out
 
 
 class ToTensor(object):
-    """16-bit PCM mono WAV -> 1-D float tensor (reference ``codes/transforms.py:130-224``).
+    """16-bit PCM mono WAV -> waveform (reference ``codes/transforms.py:130-224``).
 
-    The reference decodes with torchaudio/sox (absent here); this loader reads PCM16 with the standard library and
-    scales to [-1, 1).  ``augment=True`` draws a tempo and a gain uniformly from the ranges exactly as the reference
-    does (``np.random.uniform``) and applies them on the host: tempo with ``wsola_tempo`` above, gain in dB, then
-    the clip and 16-bit rounding sox's ``-b 16`` output implies.  sox itself is not available, so the augmented
-    waveform is the same kind of signal, not the same samples."""
+    The reference decodes with torchaudio and, with ``augment=True``, pipes every training clip through
+    ``sox ... tempo T gain G`` (T, G drawn uniformly from the ranges, printed with three decimals).  Here a loader worker
+    only READS the file's int16 samples and DRAWS (tempo, gain) exactly as the reference does (``np.random.uniform``,
+    tempo first): with ``defer=True`` (what the training loader uses) it returns a ``PCMClip`` and the decode + WSOLA
+    tempo + gain + 16-bit requantisation run on the GPU for the whole minibatch after collate; with ``defer=False``
+    (the reference's per-clip contract) the same kernels run at once and a 1-D float tensor comes back.  There is no
+    host implementation in the product; ``oracle/audio.py`` specifies the arithmetic (sox itself is absent from the
+    reference tree, so the tempo change is the published WSOLA algorithm with sox's defaults, not sox's samples)."""
 
-    def __init__(self, sample_rate=16000, augment=False, tempo_range=(0.85, 1.15), gain_range=(-6, 8)):
+    def __init__(self, sample_rate=16000, augment=False, tempo_range=(0.85, 1.15), gain_range=(-6, 8), defer=False,
+                 device='cuda'):
         self.sample_rate, self.augment = sample_rate, augment
         self.tempo_range, self.gain_range = tempo_range, gain_range
+        self.defer, self.device = defer, device
 
     def _load(self, path):
         import wave
@@ -153,18 +170,19 @@ class ToTensor(object):
             assert w.getframerate() == self.sample_rate, 'sample rate mismatch'
             assert w.getsampwidth() == 2 and w.getnchannels() == 1, 'expected 16-bit mono PCM'
             pcm = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2')
-        return pcm.astype('float32') / 32768.0
+        return torch.from_numpy(pcm.astype(np.int16, copy=True))
 
     def __call__(self, path):
         import numpy as np
-        y = self._load(path)
+        clip = PCMClip(self._load(path))
         if self.augment:
-            tempo = np.random.uniform(low=self.tempo_range[0], high=self.tempo_range[1])
-            gain = np.random.uniform(low=self.gain_range[0], high=self.gain_range[1])
-            y = wsola_tempo(y, float('{:.3f}'.format(tempo)), self.sample_rate)      # sox got three decimals
-            y = y * np.float32(10.0 ** (float('{:.3f}'.format(gain)) / 20.0))
-            y = np.clip(np.round(y * 32768.0), -32768, 32767).astype('float32') / 32768.0
-        return torch.from_numpy(np.ascontiguousarray(y))
+            clip.tempo = float(np.random.uniform(low=self.tempo_range[0], high=self.tempo_range[1]))
+            clip.gain_db = float(np.random.uniform(low=self.gain_range[0], high=self.gain_range[1]))
+        if self.defer:
+            return clip
+        batch = RawAudioBatch.from_clips([clip]).to(self.device)
+        wav, _ = ops.decode_augment(batch.pcm, batch.offsets, batch.tempos, batch.gains_db, self.sample_rate)
+        return wav.cpu()
 
     def __repr__(self):
         return '{}(sample_rate={}, augment={}, tempo_range={}, gain_range={})'.format(

@@ -24,10 +24,12 @@ NUM_CLASSES = {'pt_BR': 43, 'en': 29}
 def get_default_transforms(data_dir, config, gpu_frontend=True):
     """Waveform loader (+ per-utterance spectrogram when ``gpu_frontend`` is False) and one ToLabel per language
     (training_utils.py:18-34).  With ``gpu_frontend`` the spectrogram runs batched on the device after collate."""
-    augment = bool(config.training.get('augment', False))       # tempo + gain on the training set only (WSOLA on the host)
+    augment = bool(config.training.get('augment', False))       # tempo + gain on the training set only
+    # gpu_frontend: workers hand on int16 clips + the drawn (tempo, gain); decode, WSOLA, gain and the spectrogram all run
+    # on the device after collate.  Otherwise the reference's per-utterance contract (each transform returns a tensor).
     tail = [] if gpu_frontend else [transforms.ToSpectrogram(librosa_compat=True)]
-    train_t = transforms.Compose([transforms.ToTensor(augment=augment)] + tail)
-    val_t = transforms.Compose([transforms.ToTensor(augment=False)] + tail)
+    train_t = transforms.Compose([transforms.ToTensor(augment=augment, defer=gpu_frontend)] + tail)
+    val_t = transforms.Compose([transforms.ToTensor(augment=False, defer=gpu_frontend)] + tail)
     target_t = [transforms.ToLabel(os.path.join(data_dir, 'labels.{}.json'.format(lang)), lang=lang,
                                    remove_accents=(lang != 'pt_BR')) for lang in config.model.langs]
     return train_t, val_t, target_t
@@ -135,6 +137,12 @@ def get_data_loaders(train_transforms, val_transforms, target_transforms, args, 
         sampler = DistributedBucketingSampler(train_set, batch_size=bsz)
     else:
         sampler = BucketingSampler(train_set, batch_size=bsz)
-    train_loader = AudioDataLoader(train_set, num_workers=args.num_workers, batch_sampler=sampler, raw_audio=raw_audio)
-    val_loader = AudioDataLoader(val_set, batch_size=bsz, num_workers=args.num_workers, raw_audio=raw_audio)
+    pin = bool(raw_audio) and torch.cuda.is_available()     # page-locked int16 batches: asynchronous uploads one bin ahead
+    train_loader = AudioDataLoader(train_set, num_workers=args.num_workers, batch_sampler=sampler, raw_audio=raw_audio,
+                                   pin_memory=pin)
+    val_loader = AudioDataLoader(val_set, batch_size=bsz, num_workers=args.num_workers, raw_audio=raw_audio,
+                                 pin_memory=pin)
+    if raw_audio and torch.cuda.is_available():
+        from ..data import DevicePrefetcher
+        train_loader, val_loader = DevicePrefetcher(train_loader), DevicePrefetcher(val_loader)
     return train_loader, val_loader

@@ -34,6 +34,25 @@ def _newer(src, dst, deps):
     return any(os.path.getmtime(p) > t for p in [src] + deps)
 
 
+def build_variant(name, flags, force=False):
+    """libds2hip_<name>.so = the release objects with gru_persist.hip recompiled with ``flags`` (tools: ``timing`` =
+    -DDS2_TIMING=1 for tools/gru_sweep.py and tools/gru_phase_timing.py).  Call build() first."""
+    src = os.path.join(HERE, 'gru_persist.hip')
+    obj = os.path.join(OBJ, 'gru_persist_%s.o' % name)
+    out = os.path.join(PKG, 'ds2hip', 'libds2hip_%s.so' % name)
+    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')] + [os.path.join(ROOT, 'include', 'ds2hip.h')]
+    if force or _newer(src, obj, deps):
+        r = subprocess.run([HIPCC] + FLAGS + list(flags) + ['-c', src, '-o', obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n%s\n%s' % (r.stdout, r.stderr))
+    objs = [os.path.join(OBJ, f[:-4] + '.o') for f in sorted(os.listdir(HERE)) if f.endswith('.hip')]
+    objs = [obj if o.endswith(os.sep + 'gru_persist.o') else o for o in objs]
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return out
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
@@ -74,3 +93,6 @@ def build(force=False, verbose=False):
 
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))
+    if '--variant' in sys.argv:
+        name = sys.argv[sys.argv.index('--variant') + 1]
+        print(build_variant(name, {'timing': ['-DDS2_TIMING=1']}[name]))

@@ -675,7 +675,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                         const int cg = c * CGW + ci;
                         const int rows = min(4, nb - 4 * cg);      // batch rows this quad really has
                         // lanes of rows past the batch (and k groups past K) read nothing: out-of-range offset -> 0
-                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (g < ng && li < rows)
+                        // (k past K = 3H in the last group is never written by anyone and the ring is not cleared between
+                        // launches: it must not be read either)
+                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (64 * g + 4 * kk < K && li < rows)
                                                             ? (cg * ng * 256 + ((g * 16 + kk) * rows + li) * 4) * 4
                                                             : OOB_OFFSET);
                     }

@@ -38,6 +38,67 @@ def spectrogram(wav, wav_offsets, t_max, normalize=True, eps=1e-9):
 
 
 
+# ----------------------------------------------------------------------------- waveform decode + augmentation
+WSOLA_MS = (82.0, 14.68, 12.0)          # sox `tempo` defaults: segment, search, overlap
+
+
+def wsola_params(sample_rate=16000):
+    seg = max(int(sample_rate * WSOLA_MS[0] / 1000.0), 4)
+    ovl = max(min(int(sample_rate * WSOLA_MS[2] / 1000.0), seg // 2), 1)
+    half = max(int(sample_rate * WSOLA_MS[1] / 1000.0) // 2, 1)
+    return seg, ovl, half
+
+
+def wsola_schedule(n, tempo, sample_rate=16000):
+    """Segment schedule of one clip (data independent): int32 array of rounded ideal input positions + output length.
+    ``tempo`` is used with three decimals, as on the reference's sox command line (codes/transforms.py:197-199)."""
+    import numpy as np
+    seg, ovl, half = wsola_params(sample_rate)
+    tempo = float('{:.3f}'.format(tempo))
+    if abs(tempo - 1.0) < 1e-6 or n <= seg + half:
+        return np.zeros(0, np.int32), n
+    hop_out = seg - ovl
+    kmax = int(n / (tempo * hop_out)) + 4
+    base = np.rint(np.cumsum(np.full(kmax, tempo * hop_out, dtype=np.float64))).astype(np.int64)   # running sum, half-even
+    dead = np.minimum(base + half, n - seg) < np.maximum(base - half, 0)
+    nseg = int(np.argmax(dead)) if dead.any() else kmax
+    return base[:nseg].astype(np.int32), (nseg + 1) * hop_out + ovl
+
+
+def decode_augment(pcm, offsets, tempos=None, gains_db=None, sample_rate=16000):
+    """pcm: concatenated int16 clips on the device; offsets: python list (B+1).  Returns (float clips concatenated,
+    new offsets list).  ``tempos`` / ``gains_db`` (per clip, or None): the training-set augmentation -- WSOLA tempo,
+    then gain in dB and 16-bit requantisation -- entirely on the device."""
+    import numpy as np
+    wav = _empty((pcm.numel(),), pcm)
+    lib.call('ds2_pcm16_to_float', pcm, pcm.numel(), wav)
+    if tempos is None and gains_db is None:
+        return wav, list(offsets)
+    bsz = len(offsets) - 1
+    lens = [offsets[i + 1] - offsets[i] for i in range(bsz)]
+    if tempos is not None:
+        sched = [wsola_schedule(n, t, sample_rate) for n, t in zip(lens, tempos)]
+        out_offs = [0]
+        for _, m in sched:
+            out_offs.append(out_offs[-1] + m)
+        boffs = np.concatenate([[0], np.cumsum([len(b) for b, _ in sched])]).astype(np.int32)
+        bases = np.concatenate([b for b, _ in sched] + [np.zeros(1, np.int32)]).astype(np.int32)
+        # one upload: int64 offsets (in, out) then the int32 schedule viewed as int64 pairs
+        meta = np.concatenate([np.asarray(offsets, np.int64), np.asarray(out_offs, np.int64)])
+        meta_d = upload_small(torch.from_numpy(meta), pcm.device)
+        sched_d = upload_small(torch.from_numpy(np.concatenate([boffs, bases])), pcm.device)
+        seg, ovl, half = wsola_params(sample_rate)
+        out = _empty((out_offs[-1],), pcm)
+        lib.call('ds2_wsola_tempo', wav, meta_d[:bsz + 1], meta_d[bsz + 1:], sched_d[bsz + 1:], sched_d[:bsz + 1], bsz,
+                 seg, ovl, half, out)
+        wav, offsets = out, out_offs
+    if gains_db is not None:
+        g = torch.tensor([10.0 ** (float('{:.3f}'.format(v)) / 20.0) for v in gains_db], dtype=torch.float32)
+        offs_d = upload_small(torch.tensor(list(offsets), dtype=torch.int64), pcm.device)
+        lib.call('ds2_gain_requantize', wav, offs_d, upload_small(g, pcm.device), bsz, wav)
+    return wav, list(offsets)
+
+
 # ----------------------------------------------------------------------------- small host <-> device transfers
 class _PinnedRing(object):
     """A few reusable page-locked staging buffers per dtype: ``tensor.pin_memory()`` allocates page-locked memory

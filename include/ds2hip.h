@@ -51,6 +51,27 @@ size_t ds2_spectrogram_ws_bytes(int B, int t_max);
 int ds2_spectrogram_fwd(const float* wav, const int64_t* wav_offsets, int B, int t_max, int normalize,
                         float eps, float* out, void* stats_ws, void* stream);
 
+/* ------------------------------------------------------------------ waveform decode + augmentation
+ * Replace the per-clip host work of ToTensor (codes/transforms.py:130-224): torchaudio.load of a 16-bit PCM
+ * file, and -- for training clips with augment=True -- `sox ... -b 16 -e si <out> tempo T gain G` through a
+ * temporary file (:185-218).  The loader ships int16 samples; these run after collate on the whole minibatch.
+ *   ds2_pcm16_to_float   out[i] = pcm[i] / 32768                                  (n samples, any concatenation)
+ *   ds2_wsola_tempo      time-scale change without pitch change (WSOLA, sox's default 82 / 14.68 / 12 ms segment /
+ *                        search / overlap -> seg, half = search/2, ovl in samples).  Clip b = x[in_offsets[b] ..
+ *                        in_offsets[b+1]) -> out[out_offsets[b] .. out_offsets[b+1]).  The segment schedule is data
+ *                        independent: bases[base_offsets[b] + k] is the rounded ideal input position of segment k
+ *                        (running sum of tempo * (seg - ovl)); zero segments = copy.  The output length follows from
+ *                        the schedule: (nseg + 1) * (seg - ovl) + ovl.  Correlations in float64, first maximum wins.
+ *                        The algorithm is specified in oracle/audio.py (sox's own implementation is not in the
+ *                        reference tree: parity with sox is not claimed).
+ *   ds2_gain_requantize  y = x * gain[b]; out = clip(rint(y * 32768), -32768, 32767) / 32768   (the gain in linear
+ *                        units, 10^(dB/20); rounding half to even), in place allowed
+ */
+int ds2_pcm16_to_float(const int16_t* pcm, size_t n, float* out, void* stream);
+int ds2_wsola_tempo(const float* x, const int64_t* in_offsets, const int64_t* out_offsets, const int32_t* bases,
+                    const int32_t* base_offsets, int B, int seg, int ovl, int half, float* out, void* stream);
+int ds2_gain_requantize(const float* x, const int64_t* offsets, const float* gain, int B, float* out, void* stream);
+
 /* ------------------------------------------------------------------ generic fp32 GEMM (MFMA)
  * C[M,N] = op(A) * op(B) + beta * C, row-major with leading dimensions.  op(A)=A (M x K, lda) or
  * A^T (A stored K x M); op(B)=B (K x N, ldb) or B^T (B stored N x K).  beta is 0 or 1.

@@ -50,15 +50,19 @@ def test_dataset_loader_and_samplers(tmp_path):
         (tmp_path / ('a%d.txt' % i)).write_text('hello world %d\n' % i)
         rows.append('a%d.wav,a%d.txt,%.3f' % (i, i, n / 16000.0))
     (tmp_path / 'm.csv').write_text('\n'.join(rows) + '\n')
-    ds = AudioDataset(str(tmp_path), str(tmp_path / 'm.csv'), Compose([ToTensor()]),
+    # workers hand on the int16 samples (+ drawn augmentation); decode / tempo / gain / STFT happen on the device
+    ds = AudioDataset(str(tmp_path), str(tmp_path / 'm.csv'), Compose([ToTensor(defer=True)]),
                       ToLabel(os.path.join(ROOT, 'data', 'labels.en.json')))
     wav, lab = ds[2]
-    assert wav.shape == (20000,) and wav.dtype == torch.float32 and lab.shape == (12, 1)
+    assert wav.pcm.shape == (20000,) and wav.pcm.dtype == torch.int16 and wav.tempo is None and lab.shape == (12, 1)
     sampler = BucketingSampler(ds, batch_size=2)
     assert [sorted(b) for b in sampler.bins] == [[0, 1], [2, 3], [4]]
-    loader = AudioDataLoader(ds, batch_sampler=sampler, raw_audio=True)
+    loader = AudioDataLoader(ds, batch_sampler=sampler, raw_audio=True, num_workers=2)
+    from codes.transforms import RawAudioBatch
     wavs, targets, pct, sizes = next(iter(loader))
-    assert len(wavs) == 2 and pct is None and sizes.tolist() == [12, 12] and targets.dtype == torch.int32
+    assert isinstance(wavs, RawAudioBatch) and len(wavs) == 2 and wavs.pcm.dtype == torch.int16
+    assert sorted(wavs.offsets[i + 1] - wavs.offsets[i] for i in range(2)) == [16000, 17000] and wavs.tempos is None
+    assert pct is None and sizes.tolist() == [12, 12] and targets.dtype == torch.int32
     for w in range(2):
         s = DistributedBucketingSampler(ds, batch_size=2, num_replicas=2, rank=w)
         assert list(s) == host.ddp_bins(5, 2, 2, w)
@@ -279,38 +283,47 @@ def test_ctc_prefix_beam_search_host_entry_point():
 
 
 def test_tempo_and_gain_augmentation(tmp_path):
-    """ToTensor(augment=True): WSOLA tempo keeps the pitch and scales the duration, the gain is in dB, draws follow
-    np.random like the reference's (codes/transforms.py:171-182)."""
-    from codes.transforms import ToTensor, wsola_tempo
+    """The augmentation's specification (oracle/audio.py: WSOLA tempo keeps the pitch and scales the duration, the gain is
+    in dB, 16-bit requantisation clips) and the product's draws: ``ToTensor(augment=True, defer=True)`` draws tempo then
+    gain with np.random like the reference (codes/transforms.py:171-182) and hands the int16 samples on untouched."""
+    from codes.transforms import RawAudioBatch, ToTensor
+    from ds2hip import ops
+    from oracle import audio as oa
     sr = 16000
     t = np.arange(3 * sr) / sr
     tone = (0.2 * np.sin(2 * np.pi * 440.0 * t)).astype(np.float32)
     for tempo in (0.85, 1.0, 1.15, 1.3):
-        y = wsola_tempo(tone, tempo, sr)
+        y = oa.wsola_tempo(tone, tempo, sr)
+        assert len(y) == oa.wsola_out_len(len(tone), tempo, sr) == ops.wsola_schedule(len(tone), tempo, sr)[1]
         assert abs(len(y) - len(tone) / tempo) < 0.1 * sr                     # duration scales by 1 / tempo
         spec = np.abs(np.fft.rfft(y * np.hanning(len(y))))
         peak = np.argmax(spec) * sr / len(y)
         assert abs(peak - 440.0) < 3.0, (tempo, peak)                          # pitch unchanged
         assert 0.8 < float(np.sqrt(np.mean(y ** 2))) / float(np.sqrt(np.mean(tone ** 2))) < 1.1
-    assert np.array_equal(wsola_tempo(tone, 1.0, sr), tone)
-    noise = np.random.default_rng(0).standard_normal(2 * sr).astype(np.float32) * 0.05
-    y = wsola_tempo(noise, 1.1, sr)
-    assert abs(len(y) - len(noise) / 1.1) < 0.1 * sr and np.isfinite(y).all()
+    assert np.array_equal(oa.wsola_tempo(tone, 1.0, sr), tone)
+    # the product's data-independent segment schedule == the oracle's plan, over the augmentation range
+    for n in (1500, 16000, 123457, 240000):
+        for tempo in (0.85, 0.9004, 0.9995, 1.0005, 1.137, 1.15):
+            plan, out_len = oa.wsola_plan(n, tempo, sr)
+            bases, m = ops.wsola_schedule(n, tempo, sr)
+            assert m == out_len and len(bases) == (0 if plan is None else len(plan)), (n, tempo)
+    loud = np.asarray([0.9, -0.9, 0.25, 1e-5, -2e-5], np.float32)
+    q = oa.gain_requantize(loud, 8.0)
+    assert q[0] == np.float32(32767 / 32768.0) and q[1] == -1.0 and abs(q[2] - 0.25 * 10 ** 0.4) < 1e-4
+    assert np.all(q * 32768 == np.round(q * 32768))                            # on the 16-bit grid
     path = str(tmp_path / 'a.wav')
     _write_wav(path, tone)
-    plain = ToTensor()(path)
+    plain = ToTensor(defer=True)(path)
+    assert plain.tempo is None and plain.gain_db is None
+    assert np.array_equal(oa.pcm16_to_float(plain.pcm.numpy()), (tone * 32767).astype('<i2').astype(np.float32) / 32768)
     np.random.seed(5)
     tempo = np.random.uniform(0.85, 1.15)
     gain = np.random.uniform(-6, 8)
     np.random.seed(5)
-    aug = ToTensor(augment=True)(path)
-    assert aug.dtype == torch.float32 and aug.ndim == 1
-    assert abs(len(aug) - len(plain) / tempo) < 0.1 * sr
-    ratio = float(aug.pow(2).mean().sqrt() / plain.pow(2).mean().sqrt())
-    assert abs(20 * np.log10(ratio) - gain) < 1.0
-    assert float(aug.abs().max()) <= 1.0
-    np.random.seed(5)
-    assert torch.equal(ToTensor(augment=True)(path), aug)                      # reproducible from the seed
+    aug = ToTensor(augment=True, defer=True)(path)
+    assert aug.tempo == tempo and aug.gain_db == gain and torch.equal(aug.pcm, plain.pcm)
+    batch = RawAudioBatch.from_clips([plain, aug])
+    assert batch.offsets == [0, 3 * sr, 6 * sr] and batch.tempos == [1.0, tempo] and batch.gains_db == [0.0, gain]
     assert 'augment=True' in repr(ToTensor(augment=True))
 
 
