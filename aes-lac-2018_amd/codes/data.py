@@ -89,13 +89,15 @@ def _collate_raw(batch):
 
 
 class DevicePrefetcher(object):
-    """Iterate a loader of ``(RawAudioBatch, targets, None, sizes)`` one minibatch AHEAD: while the GPU works on step i
-    the int16 samples of step i+1 cross PCIe on a copy stream (from page-locked memory when the loader pins), so the
-    training step never waits for an upload.  The consumer (``BatchSpectrogram``) waits on the batch's ``ready`` event
-    on its own stream.  Batches that are not ``RawAudioBatch`` pass through unchanged."""
+    """Iterate a loader of ``(RawAudioBatch, targets, None, sizes)`` one minibatch AHEAD, on a side stream: while the
+    GPU trains on step i, the int16 samples of step i+1 cross PCIe (from page-locked memory when the loader pins) and --
+    when a ``frontend`` (``BatchSpectrogram``) is attached -- are decoded, tempo-changed, gain-scaled and turned into
+    the log-spectrogram there too, so the training stream never waits for an upload or for the (sequential per clip)
+    WSOLA search.  What is yielded carries a ``ready`` event (``RawAudioBatch.ready`` / ``inputs._ds2_ready``) that the
+    consumer's stream waits on.  Batches that are not ``RawAudioBatch`` pass through unchanged."""
 
-    def __init__(self, loader, device='cuda'):
-        self.loader, self.device = loader, torch.device(device)
+    def __init__(self, loader, device='cuda', frontend=None):
+        self.loader, self.device, self.frontend = loader, torch.device(device), frontend
         self.stream = torch.cuda.Stream(device=self.device)
 
     def __len__(self):
@@ -112,9 +114,15 @@ class DevicePrefetcher(object):
             return batch
         with torch.cuda.stream(self.stream):
             dev = wavs.to(self.device, non_blocking=True)
+            dev._host = wavs                         # keep the page-locked source alive until the copy has run
+            if self.frontend is not None:
+                inputs, pct = self.frontend(dev)
+                inputs._ds2_ready = torch.cuda.Event()
+                inputs._ds2_ready.record(self.stream)
+                inputs._ds2_src = dev
+                return (inputs, batch[1], pct, batch[3])
             dev.ready = torch.cuda.Event()
             dev.ready.record(self.stream)
-            dev._host = wavs                         # keep the page-locked source alive until the copy has run
         return (dev,) + tuple(batch[1:])
 
     def __iter__(self):
@@ -127,3 +135,13 @@ class DevicePrefetcher(object):
             cur, nxt = nxt, self._stage(batch)
             yield cur
         yield nxt
+
+
+def wait_ready(inputs):
+    """Make the current stream wait for a tensor a ``DevicePrefetcher`` produced on its side stream (no-op otherwise)."""
+    ev = getattr(inputs, '_ds2_ready', None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+        inputs.record_stream(torch.cuda.current_stream())
+        inputs._ds2_ready = None
+    return inputs

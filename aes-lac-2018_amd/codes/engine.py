@@ -27,6 +27,7 @@ import torch.distributed as dist
 from ds2hip import ops
 
 from .ctc import ctc_costs_and_grad
+from .data import wait_ready
 
 LOG = logging.getLogger('aes-lac-2018')
 
@@ -128,7 +129,7 @@ class Trainer(object):
         inputs, targets, input_percentages, target_sizes = batch
         if self.frontend is not None and not isinstance(inputs, torch.Tensor):   # list of clips or a RawAudioBatch
             inputs, input_percentages = self.frontend(inputs)          # raw clips -> device spectrograms
-        inputs = inputs.to(self.device, non_blocking=True)
+        inputs = wait_ready(inputs).to(self.device, non_blocking=True)
         self.data_time = time.time() - t0
         bsz = inputs.shape[0]
 
@@ -242,7 +243,7 @@ class Evaluator(object):
         self.model.eval()
         with torch.no_grad():
             inputs, targets, input_percentages, target_sizes = batch
-            out = self.model(inputs.to(self.device))                     # (B,T,A) probabilities
+            out = self.model(wait_ready(inputs).to(self.device))         # (B,T,A) probabilities
             out_sizes = sanitize_inputs(out.shape[1], input_percentages)
             return out, targets.to('cpu'), out_sizes, target_sizes.to('cpu')
 

@@ -155,9 +155,12 @@ def download_small(dev_tensor):
 
 
 def spin_wait(event):
-    """Busy-wait on an event: a blocking ``synchronize()`` sleeps on an interrupt and wakes up ~0.1 ms late."""
+    """Poll an event instead of a blocking ``synchronize()`` (which sleeps on an interrupt and wakes up ~0.1 ms late).
+    ``sleep(0)`` hands the GIL to any other thread that wants it -- the DataLoader's pin-memory thread, a prefetcher --
+    and returns at once when none does: a bare ``while not query(): pass`` starves them for the whole step."""
+    import time
     while not event.query():
-        pass
+        time.sleep(0)
 
 
 def low_priority_stream(device):

@@ -76,21 +76,35 @@ def out_steps_of(bin_):
     return ((t_in + 9) // 2 - 9) * len(bin_[0])      # padded output steps actually computed
 
 
-def cpu_baseline(plan, budget_s=25.0):
-    """The oracle (stock PyTorch CPU ops, numerically the reference) timed on the host cores: one bounded
-    training step (frontend -> fwd -> CTC -> bwd -> clip -> SGD) on the shortest bin(s)."""
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(plan, budget_s=60.0, full=False):
+    """The oracle (stock PyTorch CPU ops, numerically the reference) timed on the host cores: full training steps
+    (frontend -> fwd -> CTC -> bwd -> clip -> SGD) on B=10 bins of the SAME workload.  Protocol:
+    2 untimed warm-up steps (the shortest bin), then timed steps on five bins spread evenly over the length range
+    (0/25/50/75/100 % of the sorted bins), shortest first; value = median of the per-step frames/s.  A CPU step on a
+    median bin takes ~40 s, so the DEFAULT run stops adding bins once `budget_s` of timed work is spent (and says how
+    many of the five it timed); --cpu-full runs all five plus one 8 x 15 s step (BASELINE configs[3]'s per-GPU shape)."""
     import torch.nn.functional as F
     from oracle import spectrogram as ospec
     from oracle.model import OracleDeepSpeech
+    # threads: torch's default (= physical cores; 128 on the 256-hardware-thread GPU box).  Forcing os.cpu_count() = 256
+    # threads, as BASELINE.md suggests, oversubscribes the cores: the oracle then needs minutes for ONE short step.
     torch.manual_seed(0)
     model = OracleDeepSpeech()
     opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
     model.train()
-    order = sorted(range(len(plan)), key=lambda i: frames_of_plan(plan[i]))
-    bins = {i: make_bin(plan[i]) for i in order[:3]}
-    frames, secs, used = 0, 0.0, []
-    for idx in order[:3]:
-        wavs, labels, lens = bins[idx]
+
+    def step(bin_):
+        wavs, labels, lens = bin_
         t0 = time.time()
         x, pct = ospec.batch_log_spectrogram(wavs)
         logits = model(torch.from_numpy(x))
@@ -101,20 +115,37 @@ def cpu_baseline(plan, budget_s=25.0):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 400)
         opt.step()
-        dt = time.time() - t0
-        if used or len(order) == 1:            # the first step is the warm-up unless it is all we can afford
-            frames += frames_of(bins[idx])
-            secs += dt
-        used.append(idx)
-        if secs + dt > budget_s and frames > 0:
+        return time.time() - t0
+
+    order = sorted(range(len(plan)), key=lambda i: frames_of_plan(plan[i]))
+    picks = [order[int(round(q * (len(order) - 1)))] for q in (0.0, 0.25, 0.5, 0.75, 1.0)]
+    warm = make_bin(plan[order[0]])
+    for _ in range(2):
+        step(warm)
+    rates, used, spent = [], [], 0.0
+    for idx in picks:
+        b = make_bin(plan[idx])
+        dt = step(b)
+        note('cpu baseline: bin of %d frames in %.1f s' % (frames_of(b), dt))
+        rates.append(frames_of(b) / dt)
+        used.append('%.1f s clips: %d frames in %.1f s' % (float(np.mean(plan[idx][1])), frames_of(b), dt))
+        spent += dt
+        if not full and spent > budget_s:
             break
-        if dt > budget_s:                       # even the warm-up blew the budget: count it
-            frames, secs = frames_of(bins[idx]), dt
-            break
-    return {'value': round(frames / secs, 1), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'oracle (torch CPU conv/BN/GRU/Linear + F.ctc_loss + clip + SGD) full training step on the '
-                      '%d shortest bins of the same workload (B=10; first step = warm-up, untimed), %d frames in %.1f s'
-                      % (len(used), frames, secs)}
+    out = {'value': round(float(np.median(rates)), 1), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'cpu_model': cpu_model_name(), 'host_cpus': os.cpu_count(),
+           'per_step_frames_per_s': [round(r, 1) for r in rates],
+           'sample': 'oracle (torch CPU conv/BN/GRU/Linear + F.ctc_loss + clip + SGD) full training steps at B=10 on %d of '
+                     'the 5 bins spread over the 1-15 s length range (2 untimed warm-up steps on the shortest bin first; '
+                     'median of per-step frames/s): %s' % (len(rates), '; '.join(used))}
+    if full:
+        rng = np.random.default_rng(7)
+        wavs = [np.clip(0.1 * rng.standard_normal(240000), -1, 1).astype(np.float32) for _ in range(8)]
+        lens = np.full(8, 210, np.int32)
+        b = (wavs, rng.integers(1, 29, size=int(lens.sum())).astype(np.int32), lens)
+        dt = step(b)
+        out['config3_8x15s'] = {'value': round(frames_of(b) / dt, 1), 'unit': 'frames/s', 'seconds': round(dt, 1)}
+    return out
 
 
 def gru_pass_roofline(model, bsz, t):
@@ -150,6 +181,124 @@ def gru_pass_roofline(model, bsz, t):
     return out
 
 
+_T0 = time.time()
+
+
+def note(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    sys.stderr.write('[bench %6.1f s] %s\n' % (time.time() - _T0, msg))
+    sys.stderr.flush()
+
+
+def make_resident(bin_, dev):
+    wavs, labels, lens = bin_
+    flat = torch.from_numpy(np.concatenate(wavs)).to(dev)
+    offs = np.concatenate([[0], np.cumsum([len(w) for w in wavs])]).astype(np.int64)
+    return flat, offs, torch.from_numpy(labels), torch.from_numpy(lens)
+
+
+def timed_steps(step, n, warmup, use_dist):
+    """W untimed steps, then EXACTLY n steps bracketed by barrier + synchronize; also the per-step host times (every
+    step ends with the one readback the reference's step has, codes/engine.py:92, so they need no extra sync)."""
+    for i in range(warmup):
+        step(i)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    per = []
+    t0 = time.time()
+    for i in range(warmup, warmup + n):
+        t1 = time.perf_counter()
+        loss = step(i)
+        per.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    return time.time() - t0, per, loss
+
+
+def secondary_shape(trainer, front, dev, bsz, bins_durations, steps=None, warmup=2, seed=900):
+    """A few steps at another BASELINE shape on the same model / trainer; ``bins_durations``: one array of clip lengths
+    per bin, visited round-robin.  Returns frames/s, ms/step and the whole-step fraction of the fp32-MFMA roof."""
+    bins = [make_bin((seed + k, d)) for k, d in enumerate(bins_durations)]
+    res = [make_resident(b, dev) for b in bins]
+    steps = steps or len(bins)
+
+    def step(i):
+        flat, offs, labels, lens = res[i % len(res)]
+        inputs, pct = front(flat, offs)
+        return trainer.update((inputs, labels, pct, lens))
+
+    dt, per, _ = timed_steps(step, steps, warmup, False)
+    idxs = [i % len(bins) for i in range(warmup, warmup + steps)]
+    fr = float(sum(frames_of(bins[i]) for i in idxs))
+    osteps = float(sum(out_steps_of(bins[i]) for i in idxs))
+    tf = osteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12
+    return {'frames_per_s': round(fr / dt, 1), 'ms_per_step': round(1e3 * dt / steps, 2),
+            'whole_step_tflops': round(tf, 2), 'whole_step_frac_of_f32_mfma_peak': round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+
+
+def loader_leg(trainer, plan, dev, workers=4):
+    """End-to-end: the SAME bins as 16-bit WAV files on disk -> AudioDataset (ToTensor draws tempo + gain, hands on
+    int16) -> DataLoader workers, page-locked batches -> DevicePrefetcher (upload one bin ahead) -> device decode +
+    WSOLA tempo + gain + STFT -> training step.  frames/s of one pass over the bins (frames counted AFTER the tempo
+    change, i.e. what the model sees), and of the loader + device frontend alone."""
+    import shutil
+    import tempfile
+    import wave
+    from codes.data import AudioDataLoader, AudioDataset, DevicePrefetcher
+    from codes.sampler import BucketingSampler
+    from codes.transforms import BatchSpectrogram, Compose, ToLabel, ToTensor
+    tmp = tempfile.mkdtemp(prefix='ds2_bench_wavs_')
+    try:
+        rows, k = [], 0
+        order = sorted(range(len(plan)), key=lambda i: frames_of_plan(plan[i]))     # a duration-sorted manifest
+        for bi in order:
+            wavs, labels, lens = make_bin(plan[bi])
+            off = 0
+            for w, n in zip(wavs, lens):
+                with wave.open(os.path.join(tmp, 'u%d.wav' % k), 'wb') as f:
+                    f.setnchannels(1)
+                    f.setsampwidth(2)
+                    f.setframerate(16000)
+                    f.writeframes((w * 32767).astype('<i2').tobytes())
+                txt = ''.join(chr(64 + int(c)) if c >= 3 else 'A' for c in labels[off:off + n])   # n label characters
+                open(os.path.join(tmp, 'u%d.txt' % k), 'w').write(txt + '\n')
+                off += n
+                rows.append('u%d.wav,u%d.txt,%.4f' % (k, k, len(w) / 16000.0))
+                k += 1
+        open(os.path.join(tmp, 'm.csv'), 'w').write('\n'.join(rows) + '\n')
+        ds = AudioDataset(tmp, os.path.join(tmp, 'm.csv'), Compose([ToTensor(augment=True, defer=True)]),
+                          ToLabel(os.path.join(ROOT, 'data', 'labels.en.json')))
+        bsz = len(plan[0][1])
+        front = BatchSpectrogram(device=dev)
+        out = {'workers': workers, 'clips': k, 'augment': 'tempo 0.85-1.15 (WSOLA) + gain -6..8 dB, on the device'}
+        note('loader leg: %d wav files written' % k)
+        sampler = BucketingSampler(ds, batch_size=bsz)
+        loader = DevicePrefetcher(AudioDataLoader(ds, batch_sampler=sampler, raw_audio=True, num_workers=workers,
+                                                  pin_memory=True, persistent_workers=workers > 0), dev, frontend=front)
+        # pass 0 is untimed (it starts the worker processes); then one pass of the loader + device frontend alone and
+        # two passes feeding the training step, each over all the bins in a fresh shuffled order
+        for epoch, name in enumerate(('warmup', 'loader_and_frontend_only', 'train', 'train')):
+            sampler.shuffle(epoch + 1)
+            frames = 0
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for inputs, targets, pct, sizes in loader:
+                frames += int(round(float(pct.sum()) * inputs.shape[1]))
+                if name == 'train':
+                    trainer.update((inputs, targets, pct, sizes))
+            torch.cuda.synchronize()
+            rate = round(frames / (time.time() - t0), 1)
+            note('loader leg pass %d (%s): %s frames/s' % (epoch, name, rate))
+            if name != 'warmup':
+                out[name + '_frames_per_s'] = max(rate, out.get(name + '_frames_per_s', 0.0))
+        del loader
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -157,6 +306,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch-size', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-full', action='store_true', help='the complete CPU protocol (5 bins + an 8 x 15 s step; ~5 min)')
+    ap.add_argument('--cpu-budget-s', type=float, default=60.0)
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary shapes and the loader leg')
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON result: RCCL prints a version banner to the C-level stdout (flushed at
@@ -196,11 +348,7 @@ def main():
     plan = bin_plan(bsz, NUM_BINS * world, world=world)
     mine = [make_bin(p) for p in plan[rank::world]]                      # every world-th bin, starting from rank
     dev = torch.device('cuda', local)
-    resident = []
-    for wavs, labels, lens in mine:                                       # inputs resident in HBM before timing
-        flat = torch.from_numpy(np.concatenate(wavs)).to(dev)
-        offs = np.concatenate([[0], np.cumsum([len(w) for w in wavs])]).astype(np.int64)
-        resident.append((flat, offs, torch.from_numpy(labels), torch.from_numpy(lens)))
+    resident = [make_resident(b, dev) for b in mine]                      # inputs resident in HBM before timing
 
     torch.manual_seed(42)
     model = DeepSpeech().to(dev)                                          # 5 x BiGRU-800, A = 29, random init
@@ -213,27 +361,37 @@ def main():
         inputs, pct = front(flat, offs)
         return trainer.update((inputs, labels, pct, lens))
 
-    for i in range(args.warmup):
-        step(i)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for i in range(args.warmup, args.warmup + args.steps):
-        loss = step(i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.time() - t0
+    note('model built, inputs resident; timing')
+    dt, per, loss = timed_steps(step, args.steps, args.warmup, use_dist)
+    note('timed region done: %.2f ms/step' % (1e3 * dt / args.steps))
     idxs = [i % len(mine) for i in range(args.warmup, args.warmup + args.steps)]
     frames = float(sum(frames_of(mine[i]) for i in idxs))
     osteps = float(sum(out_steps_of(mine[i]) for i in idxs))
+    step_rates = sorted(frames_of(mine[i]) / t for i, t in zip(idxs, per))      # this rank's per-step frames/s
+    per_sorted = sorted(per)
     if use_dist:
         t = torch.tensor([dt, frames, osteps], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, frames, osteps = float(tmax[0]), float(t[1]), float(t[2])
+
+    # BASELINE configs[3] at N > 1: 64 x 15 s over 8 GPUs = 8 clips of 15 s per rank (every rank, same barrier protocol)
+    cfg3 = None
+    if world > 1 and not args.no_extras:
+        c3 = [make_resident(make_bin((7000 + rank * 10 + k, np.full(8, 15.0))), dev) for k in range(2)]
+
+        def step3(i):
+            flat, offs, labels, lens = c3[i % 2]
+            inputs, pct = front(flat, offs)
+            return trainer.update((inputs, labels, pct, lens))
+
+        dt3, _, _ = timed_steps(step3, 8, 2, use_dist)
+        t3 = torch.tensor([dt3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        cfg3 = {'workload': 'BASELINE configs[3]: 8 x 15 s per GPU (64 x 15 s at 8 GPUs)', 'steps': 8,
+                'frames_per_s': round(8 * 8 * 1501 * world / float(t3[0]), 1),
+                'ms_per_step': round(1e3 * float(t3[0]) / 8, 2)}
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -262,15 +420,24 @@ def main():
     model.train()
     step_tflops = osteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12 / world    # per GPU, padded steps included
     t_mean = int(round(np.mean([out_steps_of(b) / len(b[0]) for b in mine])))
+    note('inference leg done')
     roof = gru_pass_roofline(model, bsz, t_mean)
+    note('roofline leg done')
     ach, dur, flop = roof['bwd']
-    traffic = None                      # HBM bytes per launch from a committed rocprofv3 --pmc run of the same shape
-    try:
-        rec = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
-        if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
-            traffic = rec['gru_bwd_persistent4_kernel']['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM-side bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of the same shape whose
+    # summary is committed under profiles/ (PMC collection cannot run inside this process); the file is named below
+    traffic, traffic_src = None, None
+    for name in ('r02_traffic.json', 'r01_traffic.json'):
+        try:
+            rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
+                traffic = rec['gru_bwd_persistent4_kernel']['traffic_bytes_per_launch']
+                traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gru_step_timing.py, ' \
+                              'not measured in this run)' % name
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    pct_of = lambda v, q: v[min(len(v) - 1, int(round(q * (len(v) - 1))))]          # noqa: E731
     result = {
         'metric': 'train frames/sec, DeepSpeech2 5xBiGRU-800',
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -281,12 +448,18 @@ def main():
                                'frontend, CTC, clip+SGD' % bsz,
                    'batch_per_gpu': bsz, 'global_batch': bsz * world, 'parallelism': 'dp%d' % world,
                    'last_loss': round(float(loss), 4),
+                   'ms_per_step_rank0': {'median': round(1e3 * pct_of(per_sorted, 0.5), 3),
+                                         'p10': round(1e3 * pct_of(per_sorted, 0.1), 3),
+                                         'p90': round(1e3 * pct_of(per_sorted, 0.9), 3)},
+                   'frames_per_s_per_step_rank0': {'median': round(pct_of(step_rates, 0.5), 1),
+                                                   'p10': round(pct_of(step_rates, 0.1), 1),
+                                                   'p90': round(pct_of(step_rates, 0.9), 1)},
                    'inference_frames_per_s_rank0': round(inf_frames / inf_dt, 1)},
         'roofline': {'bound': 'mfma',
                      'kernel': 'gru_bwd_persistent4_kernel (one launch = all T=%d steps of a BiGRU layer, both '
                                'directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic,
+                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                      'avg_launch_us': round(dur * 1e6, 1), 'us_per_time_step': round(dur * 1e6 / t_mean, 3),
                      'flop_per_launch': flop,
                      'fwd_kernel_tflops': round(roof['fwd'][0], 3),
@@ -294,8 +467,22 @@ def main():
                      'whole_step_tflops_per_gpu': round(step_tflops, 3),
                      'whole_step_frac_of_f32_mfma_peak': round(step_tflops / PEAK_F32_MFMA_TFLOPS, 5)},
     }
+    if cfg3 is not None:
+        result['config']['config3'] = cfg3
+    if world == 1 and not args.no_extras:
+        # the other single-GPU BASELINE shapes on the same model, a few steps each
+        p32 = bin_plan(32, 8, seed=43)                      # a length-sorted corpus cut into bins of 32, as BucketingSampler does
+        result['config']['other_shapes'] = {
+            'B32_1to15s (configs[2])': secondary_shape(trainer, front, dev, 32, [p[1] for p in p32]),
+            'B8_x_15s (configs[3] per GPU)': secondary_shape(trainer, front, dev, 8, [np.full(8, 15.0)] * 2),
+            'B64_x_15s (fixed worst case)': secondary_shape(trainer, front, dev, 64, [np.full(64, 15.0)] * 2, steps=4,
+                                                            warmup=1),
+        }
+        note('other shapes done')
+        result['config']['loader'] = loader_leg(trainer, plan, dev)
+        note('loader leg done')
     if not args.no_cpu_baseline and world == 1:      # the CPU oracle is timed beside the GPU at N = 1 only
-        result['cpu_baseline'] = cpu_baseline(plan)
+        result['cpu_baseline'] = cpu_baseline(plan, budget_s=args.cpu_budget_s, full=args.cpu_full)
     if use_dist:
         dist.destroy_process_group()
     sys.stdout.flush()

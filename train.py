@@ -163,6 +163,9 @@ def main(argv=None):
     criterion = [warp_CTCLoss()]
     decoder = GreedyDecoder(target_t[0].label_encoder)
     frontend = BatchSpectrogram(device=device)
+    for ld in (train_loader, val_loader):            # decode + augmentation + STFT of the NEXT bin run on the prefetch stream
+        if hasattr(ld, 'frontend'):
+            ld.frontend = frontend
     steps_per_epoch = max(1, len(train_loader))
     skip_n = int(start_iteration % steps_per_epoch)               # train.py:198-200
     trainer = create_trainer(model, optimizer, criterion, device, skip_n=skip_n, frontend=frontend,
@@ -172,9 +175,10 @@ def main(argv=None):
 
     def eval_loader(loader):
         def gen():
-            for wavs, targets, _, sizes in loader:
-                inputs, pct = frontend(wavs)
-                yield inputs, targets, pct, sizes
+            for wavs, targets, pct, sizes in loader:
+                if not isinstance(wavs, torch.Tensor):               # (a prefetcher with the frontend attached yields tensors)
+                    wavs, pct = frontend(wavs)
+                yield wavs, targets, pct, sizes
         return evaluator.run(gen())
 
     def payload(epoch, iteration):
