@@ -11,6 +11,8 @@
 //   A "k-contiguous"  A[m*lda + k]   (trans_a = 0)     A "m-contiguous"  A[k*lda + m]  (trans_a = 1)
 //   B "n-contiguous"  B[k*ldb + n]   (trans_b = 0)     B "k-contiguous"  B[n*ldb + k]  (trans_b = 1)
 // Numerics: exact fp32 FMA chain in k order per 2-k MFMA (same as fmaf accumulation).
+#include <stdlib.h>
+
 #include "ds2_common.h"
 
 namespace {
@@ -70,6 +72,35 @@ __device__ __forceinline__ void load_slab(__amdgpu_buffer_rsrc_t rs, int ld, int
             }
         }
     }
+}
+
+// Fast path of load_slab for whole slabs: the per-lane byte offsets of a tile do not change from slab to slab, only a
+// wave-uniform advance does -- it goes into the buffer instruction's SCALAR offset.  Lanes outside the tile keep an
+// out-of-range vector offset (the range check ignores the scalar offset), so the loop body holds no address arithmetic:
+// the general form above recomputes and re-checks every offset for every slab, ~80 vector instructions in front of each
+// slab's first MFMA.  Valid when every 16-byte chunk is wholly inside or outside the tile (VEC and xmax % 4 == 0 for the
+// x-contiguous form) and the slab does not cross kmax.
+template <bool KCONTIG>
+__device__ __forceinline__ void slab_voffsets(int ld, int x0, int xmax, int tid, int (&voff)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (KCONTIG) {
+            const int x = x0 + tid / (BK / 4) + (1024 / BK) * i;
+            voff[i] = x < xmax ? (x * ld + (tid & (BK / 4 - 1)) * 4) * 4 : OOB;
+        } else {
+            const int x = x0 + (tid & 31) * 4;
+            voff[i] = x < xmax ? (((tid >> 5) + 8 * i) * ld + x) * 4 : OOB;
+        }
+    }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ int slab_soffset(int ld, int k0) {
+    return KCONTIG ? k0 * 4 : k0 * ld * 4;
+}
+__device__ __forceinline__ void load_slab_fast(__amdgpu_buffer_rsrc_t rs, const int (&voff)[NI], int soff, f32x4 (&r)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0));
 }
 
 template <bool KCONTIG>
@@ -185,6 +216,174 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, c
         }
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// v2 main loop: THREE LDS slab buffers.  In iteration s the MFMAs read slab s, the registers loaded one iteration ago
+// (slab s+2) are written to the third buffer, the global loads of slab s+3 are issued, and the first operands of slab
+// s+1 -- written an iteration ago, already behind a barrier -- are fetched BEFORE this iteration's barrier, so the
+// first MFMA after the barrier has its operands and no wave waits on a global load it issued moments ago.  (The
+// two-buffer loop above stalls every 16-deep slab on the vmcnt wait + LDS store + barrier + first ds_read chain:
+// SQ_WAIT_ANY 16 % of wave cycles, MFMA pipe ~75 % busy on 4096^3.)
+//
+// Work decomposition: a workgroup runs one or two PIECES = (tile, slab range).  Data-parallel pieces own a whole tile
+// and store it; when the tile count is not a multiple of the resident slots (2 per CU), the tiles of the last, partial
+// round are cut "stream-K" style into equal runs of (tile, slab) units -- one run per slot, crossing at most one tile
+// boundary -- and accumulated with float atomics into rows the launcher zeroed: 1292 tiles on 512 slots take
+// 2.54 tile-times instead of 3.
+// ----------------------------------------------------------------------------------------------------------
+template <bool A_KCONTIG, bool B_KCONTIG, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                             const float* __restrict__ B, int ldb,
+                                                             float* __restrict__ C, int ldc, float beta, int tiles_n,
+                                                             int dp_tiles, int sk_units, int sk_total,
+                                                             unsigned int a_bytes, unsigned int b_bytes) {
+    __shared__ __attribute__((aligned(16))) float lds[3][2][BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nslab_all = (K + BK - 1) / BK;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, b_bytes, 0x00020000);
+
+    int u0 = 0, u1 = 0;                                // stream-K unit range of this workgroup (empty for DP workgroups)
+    const bool is_dp = (int)blockIdx.x < dp_tiles;
+    if (!is_dp) {
+        u0 = ((int)blockIdx.x - dp_tiles) * sk_units;
+        u1 = min(u0 + sk_units, sk_total);
+    }
+#pragma unroll 1
+    for (int piece = 0; piece < 2; ++piece) {
+        int tile, s_beg, s_end;
+        if (is_dp) {
+            if (piece == 1) break;
+            // XCD-aware order over the data-parallel tiles (workgroups b and b + 8 share an L2)
+            const int nwg = dp_tiles, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            const int qd = nwg >> 3, rm = nwg & 7;
+            tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+            s_beg = 0;
+            s_end = nslab_all;
+        } else {
+            if (u0 >= u1) break;
+            tile = dp_tiles + u0 / nslab_all;
+            s_beg = u0 % nslab_all;
+            s_end = min(nslab_all, s_beg + (u1 - u0));
+            u0 += s_end - s_beg;
+        }
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        const int nslab = s_end - s_beg;
+        const int kbeg = s_beg * BK, kend = min(K, s_end * BK);
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        f32x4 ra[NI], rb[NI];
+        int va[NI], vb[NI];
+        slab_voffsets<A_KCONTIG>(lda, m0, M, tid, va);
+        slab_voffsets<B_KCONTIG>(ldb, n0, N, tid, vb);
+        // whole slabs of a tile whose 16-byte chunks never straddle its edge take the fast loads
+        const bool fast_ok = VEC && (A_KCONTIG || (M & 3) == 0) && (B_KCONTIG || (N & 3) == 0);
+        auto fetch = [&](int k0) {
+            if (fast_ok && k0 + BK <= kend) {
+                load_slab_fast(rsa, va, slab_soffset<A_KCONTIG>(lda, k0), ra);
+                load_slab_fast(rsb, vb, slab_soffset<B_KCONTIG>(ldb, k0), rb);
+            } else {
+                load_slab<A_KCONTIG, VEC>(rsa, lda, m0, M, k0, kend, tid, ra);
+                load_slab<B_KCONTIG, VEC>(rsb, ldb, n0, N, k0, kend, tid, rb);
+            }
+        };
+        __syncthreads();                               // (second piece: the previous piece's LDS reads are done)
+        fetch(kbeg);
+        store_slab<A_KCONTIG>(lds[0][0], tid, ra);
+        store_slab<B_KCONTIG>(lds[0][1], tid, rb);
+        if (nslab > 1) {
+            fetch(kbeg + BK);
+            store_slab<A_KCONTIG>(lds[1][0], tid, ra);
+            store_slab<B_KCONTIG>(lds[1][1], tid, rb);
+        }
+        if (nslab > 2) {                               // slab 2 stays in registers until iteration 0 stores it
+            fetch(kbeg + 2 * BK);
+        }
+        __syncthreads();
+        const int aoff = wm * 64 + lr + lh * LDT, boff = wn * 64 + lr + lh * LDT;
+        float pa0 = lds[0][0][aoff], pa1 = lds[0][0][aoff + 32], pb0 = lds[0][1][boff], pb1 = lds[0][1][boff + 32];
+        int cur = 0;
+        for (int s = 0; s < nslab; ++s) {
+            const float* as = lds[cur][0] + aoff;
+            const float* bs = lds[cur][1] + boff;
+            const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = pa0, a1 = pa1, b0 = pb0, b1 = pb1;
+                if (kk + 2 < BK) {                     // next k pair of this slab
+                    pa0 = as[(kk + 2) * LDT];
+                    pa1 = as[(kk + 2) * LDT + 32];
+                    pb0 = bs[(kk + 2) * LDT];
+                    pb1 = bs[(kk + 2) * LDT + 32];
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                // pin the order "operand reads of the NEXT k pair, then the four MFMAs of this one": left alone the
+                // scheduler sinks the reads behind the MFMAs, right in front of their wait, and every k pair exposes an
+                // LDS round trip
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // DS reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // MFMA
+                if (kk == BK - 6 && s + 2 < nslab) {   // registers (slab s+2, loaded an iteration ago) -> third buffer
+                    store_slab<A_KCONTIG>(lds[nx2][0], tid, ra);
+                    store_slab<B_KCONTIG>(lds[nx2][1], tid, rb);
+                    if (s + 3 < nslab) fetch(kbeg + (s + 3) * BK);
+                }
+            }
+            if (s + 1 < nslab) {                       // first operands of slab s+1: its buffer is a barrier old
+                pa0 = lds[nxt][0][aoff];
+                pa1 = lds[nxt][0][aoff + 32];
+                pb0 = lds[nxt][1][boff];
+                pb1 = lds[nxt][1][boff + 32];
+            }
+            __syncthreads();
+            cur = nxt;
+        }
+
+        const bool atomic = !is_dp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + lr;
+                if (n >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M) {
+                        float* c = C + (size_t)m * ldc + n;
+                        if (atomic)
+                            atomicAdd(c, acc[i][j][r]);
+                        else
+                            *c = (beta != 0.f) ? acc[i][j][r] + beta * (*c) : acc[i][j][r];
+                    }
+                }
+            }
+    }
+}
+
+// resident slots for the v2 kernel on the current device: 2 workgroups per CU (launch bounds), cached per device
+inline int gemm_slots() {
+    static int slots[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
+    if (slots[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        slots[dev] = 2 * n;
+    }
+    return slots[dev];
+}
+
 template <bool AK, bool BKc>
 int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float beta,
            int split_k, hipStream_t st) {
@@ -203,6 +402,44 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
         }
     }
     if (split_k < 1) split_k = 1;
+    const bool vec0 = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
+                      ((!AK && !BKc) || K % 4 == 0);
+    static const bool v2_on = !(getenv("DS2_GEMM_V2") && getenv("DS2_GEMM_V2")[0] == '0');    // A/B timing switch
+    const int tiles_all = tm * tn, slots_all = gemm_slots();
+    if (split_k == 1 && v2_on && tiles_all > slots_all && tiles_all % slots_all != 0 && ds2_cdiv(K, BK) >= 16 && beta == 0.f) {
+        // whole-tile workgroups for as many complete rounds of the resident slots as there are, stream-K runs for the rest
+        const unsigned long long abytes = 4ull * (AK ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
+        const unsigned long long bbytes = 4ull * (BKc ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
+        if (abytes >= 0x7FFFFFF0ull || bbytes >= 0x7FFFFFF0ull) return -1;
+        const int tiles = tm * tn, slots = gemm_slots(), nslab = ds2_cdiv(K, BK);
+        int dp = tiles, sk_wgs = 0, sk_units = 0, sk_total = 0;
+        const int rem = tiles % slots;
+        // (when the tiles fill whole rounds the two-buffer kernel below is ~4 % faster on 4096^3: its shorter loop body
+        // wins once there is no partial round to balance)
+        const bool hybrid = tiles > slots && rem != 0 && nslab >= 16 && beta == 0.f;
+        if (hybrid) {
+            dp = tiles - rem;
+            sk_total = rem * nslab;
+            sk_wgs = sk_total / 16 < slots ? sk_total / 16 : slots;         // at least 16 slabs per run
+            if (sk_wgs < 1) sk_wgs = 1;
+            sk_units = ds2_cdiv(sk_total, sk_wgs);
+            if (sk_units > nslab) {                                          // a run may cross ONE tile boundary only
+                sk_units = nslab;
+            }
+            sk_wgs = ds2_cdiv(sk_total, sk_units);
+            const int r0 = (dp / tn) * BM;                                   // first row that holds a stream-K tile
+            (void)hipMemset2DAsync(C + (size_t)r0 * ldc, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float),
+                                   M - r0, st);
+        }
+        dim3 grid(dp + sk_wgs), block(256);
+        if (vec0)
+            hipLaunchKernelGGL((gemm_f32_v2_kernel<AK, BKc, true>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc,
+                               beta, tn, dp, sk_units, sk_total, (unsigned int)abytes, (unsigned int)bbytes);
+        else
+            hipLaunchKernelGGL((gemm_f32_v2_kernel<AK, BKc, false>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc,
+                               beta, tn, dp, sk_units, sk_total, (unsigned int)abytes, (unsigned int)bbytes);
+        return 0;
+    }
     int kper = ds2_cdiv(ds2_cdiv(K, split_k), BK) * BK;
     if (kper < BK) kper = BK;
     const int nsplit = ds2_cdiv(K, kper);

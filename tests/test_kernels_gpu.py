@@ -24,7 +24,8 @@ def _t(a):
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize('m,n,k', [(128, 128, 16), (300, 200, 100), (37, 29, 800), (1000, 4800, 672),
-                                   (29, 800, 555), (5, 7, 3), (257, 129, 33)])
+                                   (29, 800, 555), (5, 7, 3), (257, 129, 33),
+                                   (4240, 4800, 800), (3001, 2999, 301), (2100, 4000, 17), (8200, 4100, 40)])
 def test_gemm_matches_fp64(ops, ta, tb, m, n, k):
     rng = np.random.default_rng(m * 7 + n * 3 + k + ta * 2 + tb)
     a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
