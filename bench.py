@@ -309,6 +309,8 @@ def main():
     ap.add_argument('--cpu-full', action='store_true', help='the complete CPU protocol (5 bins + an 8 x 15 s step; ~5 min)')
     ap.add_argument('--cpu-budget-s', type=float, default=60.0)
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary shapes and the loader leg')
+    ap.add_argument('--fixed-seconds', type=float, default=0.0,
+                    help='profiling aid: every clip this long (e.g. --batch-size 64 --fixed-seconds 15 = the fixed worst case)')
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON result: RCCL prints a version banner to the C-level stdout (flushed at
@@ -346,6 +348,8 @@ def main():
 
     bsz = args.batch_size
     plan = bin_plan(bsz, NUM_BINS * world, world=world)
+    if args.fixed_seconds > 0:
+        plan = [(seed, np.full(bsz, args.fixed_seconds)) for seed, _ in plan[:4 * world]]
     mine = [make_bin(p) for p in plan[rank::world]]                      # every world-th bin, starting from rank
     dev = torch.device('cuda', local)
     resident = [make_resident(b, dev) for b in mine]                      # inputs resident in HBM before timing
@@ -443,8 +447,9 @@ def main():
         'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: librispeech-from_scratch.json, 5xBiGRU-800 A=29, batch %d per GPU, '
-                               '16 kHz clips uniform 1-15 s in length-sorted bins, full train step incl. GPU STFT '
-                               'frontend, CTC, clip+SGD' % bsz,
+                               '16 kHz clips %s, full train step incl. GPU STFT frontend, CTC, clip+SGD'
+                               % (bsz, 'uniform 1-15 s in length-sorted bins' if args.fixed_seconds <= 0
+                                  else 'all %.1f s long' % args.fixed_seconds),
                    'batch_per_gpu': bsz, 'global_batch': bsz * world, 'parallelism': 'dp%d' % world,
                    'last_loss': round(float(loss), 4),
                    'ms_per_step_rank0': {'median': round(1e3 * pct_of(per_sorted, 0.5), 3),
