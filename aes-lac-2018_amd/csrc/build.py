@@ -34,6 +34,22 @@ def _newer(src, dst, deps):
     return any(os.path.getmtime(p) > t for p in [src] + deps)
 
 
+def build_gemm_variant(name, flags):
+    """libds2hip_<name>.so with gemm.hip recompiled with ``flags`` (tools/gemm_ablate.py)."""
+    src = os.path.join(HERE, 'gemm.hip')
+    obj = os.path.join(OBJ, 'gemm_%s.o' % name)
+    out = os.path.join(PKG, 'ds2hip', 'libds2hip_%s.so' % name)
+    r = subprocess.run([HIPCC] + FLAGS + list(flags) + ['-c', src, '-o', obj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed:\n%s\n%s' % (r.stdout, r.stderr))
+    objs = [os.path.join(OBJ, f[:-4] + '.o') for f in sorted(os.listdir(HERE)) if f.endswith('.hip')]
+    objs = [obj if o.endswith(os.sep + 'gemm.o') else o for o in objs]
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return out
+
+
 def build_variant(name, flags, force=False):
     """libds2hip_<name>.so = the release objects with gru_persist.hip recompiled with ``flags`` (tools: ``timing`` =
     -DDS2_TIMING=1 for tools/gru_sweep.py and tools/gru_phase_timing.py).  Call build() first."""
