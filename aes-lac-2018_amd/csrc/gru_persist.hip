@@ -34,8 +34,19 @@ __device__ long long ds2_tbuf[32 * 8];
 extern "C" int ds2_debug_read_timing(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ds2_tbuf), sizeof(long long) * 32 * 8) == hipSuccess ? 0 : -1;
 }
+__device__ unsigned int ds2_retries;            // fragments re-loaded by the canary protocol (all kernels)
+extern "C" int ds2_debug_read_retries(unsigned int* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ds2_retries), sizeof(unsigned int)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned int z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ds2_retries), &z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define DS2_RETRY() do { if (lane == 0) __hip_atomic_fetch_add(&ds2_retries, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
 #define DS2_TICK(i) do {} while (0)
+#define DS2_RETRY() do {} while (0)
 #endif
 
 namespace {
@@ -100,6 +111,29 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 }
 __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// "Signal first, drain later" hand-off (4x4x1 forms, CAN = true).  In the drained protocol a step's chain is
+//   stores -> wait for their acks (~0.45 us) -> barrier -> arrival add -> (others) poll -> load,
+// four dependent memory operations.  Here the arrival add goes out right behind the stores and the wave waits for the
+// acks AFTERWARDS, while it would otherwise sit idle waiting for the other workgroups' arrivals.  A consumer may
+// therefore see the count before a payload has landed; to detect that, every ring position is overwritten with
+// CANARY_BITS (a NaN pattern no arithmetic produces) one step before its next payload, by the same lane (same address:
+// the two stores stay ordered), three slots deep, and a wave that finds the pattern in a fragment loads its fragments
+// again.  What the counter still guarantees: the canary of the slot has landed (each step's stores are drained before the
+// next step's arrival add), so the slot's three-steps-old payload can never be mistaken for the new one.
+constexpr unsigned int CANARY_BITS = 0xFFFFFFFFu;
+__device__ __forceinline__ void store_canary(float* p) {
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), CANARY_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one 16-byte write-through (sc1) store through a WAVE-UNIFORM descriptor + per-lane byte offset (a per-lane descriptor
+// would make the compiler emit a waterfall loop over the lanes)
+__device__ __forceinline__ void store_sc1_b128(__amdgpu_buffer_rsrc_t rs, int byte_off, u32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ bool has_canary(f32x4 v) {
+    const u32x4 u = __builtin_bit_cast(u32x4, v);
+    return (u[0] == CANARY_BITS) | (u[1] == CANARY_BITS) | (u[2] == CANARY_BITS) | (u[3] == CANARY_BITS);
 }
 
 // wave 0 only (all 64 lanes call it): lane l < NSHARD polls shard l until it holds step * (slices in that shard)
@@ -584,7 +618,7 @@ constexpr int RED4_PITCH = NWP * 4 + 4;   // floats per reduced value in LDS: 32
 // per step and waits for 50 / 34 producers instead of 100.  The launcher picks the form with a cost model fitted to
 // measurements: a step costs ~0.40 us per (batch quad x 8 units) of MFMA + fold work and ~0.34 us per 4 batch rows
 // of hand-off loads per workgroup.
-template <int NGI, int NRG>
+template <int NGI, int NRG, bool CAN>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        const float* __restrict__ hout,
                                                                        const float* __restrict__ d_out,
@@ -612,7 +646,11 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     const int ncg = (nb + 3) >> 2;
     const int ng = (K + 63) >> 6;                       // 64-wide k groups
     const int slot_floats = ng * 64 * nb;               // a partial last quad keeps only its nb & 3 rows
-    float* my_ring = ring + (size_t)(dir * NPART + part) * 2 * ((size_t)ng * 64 * bper);
+    constexpr int NSLOT = CAN ? 3 : 2;
+    // the wave that signals and polls: with the signal-first protocol the LAST wave, which has few or no gate threads (96 of
+    // them in waves 0-1 at B = 10), so its arrival add does not queue behind its own hand-off stores
+    constexpr int SIGW = CAN ? NWP - 1 : 0;
+    float* my_ring = ring + (size_t)(dir * NPART + part) * NSLOT * ((size_t)ng * 64 * bper);
     if (nb <= 0) {                                      // an empty batch part: nobody waits for it
         if (tid == 0) leave_kernel(sync);
         return;
@@ -636,7 +674,19 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     float dhz = 0.f;
     unsigned int* shards = &sync->arrive[dir][part][0][0];
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    // this gate thread's three positions inside a ring slot (k index of unit j in gate g is g*H + j)
+    const int rows4g = min(4, nb - (nn & ~3)) * 4;      // floats per k quad of this thread's batch quad
+    const int hoff = (nn >> 2) * ng * 256 + (nn & 3) * 4;
+    const int ho0 = hoff + (gj >> 2) * rows4g + (gj & 3), ho1 = hoff + ((H + gj) >> 2) * rows4g + ((H + gj) & 3),
+              ho2 = hoff + ((2 * H + gj) >> 2) * rows4g + ((2 * H + gj) & 3);
+    if (CAN && gate_ok) {                               // slot 0 may hold an earlier launch's payload
+        store_canary(my_ring + ho0);
+        store_canary(my_ring + ho1);
+        store_canary(my_ring + ho2);
+    }
+    if (CAN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int scur = 0, sprev = NSLOT - 1;                    // slot written this step / read this step (= last step's)
 
     for (int s = 0; s < T; ++s) {
         DS2_TICK(0);
@@ -644,29 +694,43 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
         float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
         size_t row = 0, gbase = 0;
-        if (gate_ok) {
-            // saved activations of step t (written by the forward pass, an earlier launch): plain loads
-            row = ((size_t)t * B + gb) * 2 + dir;
-            gbase = row * 3 * H + gj;
-            dh = d_out[((size_t)t * B + gb) * H + gj];
-            r = G[gbase];
-            z = G[gbase + H];
-            n = G[gbase + 2 * H];
-            gn = ghn[row * H + gj];
-            if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
-        }
+        auto early_loads = [&]() {
+            if (gate_ok) {
+                // saved activations of step t (written by the forward pass, an earlier launch): plain loads
+                row = ((size_t)t * B + gb) * 2 + dir;
+                gbase = row * 3 * H + gj;
+                dh = d_out[((size_t)t * B + gb) * H + gj];
+                r = G[gbase];
+                z = G[gbase + H];
+                n = G[gbase + 2 * H];
+                gn = ghn[row * H + gj];
+                if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
+            }
+        };
+        // signal-first: the polling wave polls FIRST, then waits for its own (by then old) stores, and only then issues
+        // these loads -- a vmcnt wait behind freshly issued HBM loads would put their latency on the step's chain
+        const bool poll_first = CAN && wave == SIGW && s > 0;
+        if (!poll_first) early_loads();
         if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+            if (!DS2_DBG(dbg, 1) && wave == SIGW && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
+            if (poll_first) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
+                early_loads();
+            }
             DS2_TICK(1);
             __syncthreads();
             DS2_TICK(2);
             if (abort_flag) return;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-                my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
+                my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
             auto chunk = [&](int c, auto nci_tag) {
                 constexpr int NCI = decltype(nci_tag)::value;
                 f32x4 bf[NCI][NGI];
+                f32x4 acc[NRG][NCI];
+                unsigned long long t_retry = 0;
+              for (;;) {
+                asm volatile("" ::: "memory");                    // a retry must issue the loads again
 #pragma unroll
                 for (int gi = 0; gi < NGI; ++gi)                   // k-group major: the MFMAs below consume in this order
 #pragma unroll
@@ -684,7 +748,6 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 // every load of the chunk goes out before the first MFMA: left alone the scheduler sinks loads in between
                 // the MFMAs and keeps only 2-5 in flight, which throttles a phase bounded by bytes in flight
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 acc[NRG][NCI];
 #pragma unroll
                 for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
@@ -698,6 +761,20 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 #pragma unroll
                             for (int rg = 0; rg < NRG; ++rg)
                                 acc[rg][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[rg][gi][e], bf[ci][gi][e], acc[rg][ci], 0, 0, 0);
+                if (!CAN) break;
+                bool stale = false;                                // a fragment whose payload had not landed yet?
+#pragma unroll
+                for (int gi = 0; gi < NGI; ++gi)
+#pragma unroll
+                    for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][gi]);
+                if (!__any(stale)) break;
+                DS2_RETRY();
+                if (t_retry == 0) t_retry = __builtin_amdgcn_s_memrealtime();
+                if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {
+                    if (lane == 0) __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+              }
                 // fold the 16 per-block partials: two DPP adds leave each 16-lane row's sum in its lanes 12..15
                 // (all the DPP adds first, as independent chains, then ONE predicated region with the stores: written value
                 // by value the compiler emits add_dpp / s_nop / mov_dpp / saveexec / add / ds_write / restore exec per value)
@@ -757,26 +834,56 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             const float dz_pre = dh * (hpv - n) * z * (1.f - z);
             const float dr_pre = dn_pre * gn * r * (1.f - r);
             dhz = dh * z;
-            {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
-                const int rows4 = min(4, nb - (nn & ~3)) * 4;   // floats per (k quad) of this batch quad
-                float* slot = my_ring + (size_t)(s & 1) * slot_floats + (size_t)(nn >> 2) * ng * 256 + (nn & 3) * 4;
-                const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
-                store_sc1(&slot[(k0 >> 2) * rows4 + (k0 & 3)], dr_pre);
-                store_sc1(&slot[(k1 >> 2) * rows4 + (k1 & 3)], dz_pre);
-                store_sc1(&slot[(k2 >> 2) * rows4 + (k2 & 3)], dn_pre * r);
+            if (!CAN) {   // hand-off copies into the ring (write-through)
+                float* slot = my_ring + (size_t)scur * slot_floats;
+                store_sc1(slot + ho0, dr_pre);
+                store_sc1(slot + ho1, dz_pre);
+                store_sc1(slot + ho2, dn_pre * r);
             }
             sv_r = dr_pre;
             sv_z = dz_pre;
             sv_n = dn_pre;
             sv_g = dn_pre * r;
         }
+        if (CAN) {
+            // Signal-first hand-off stores: the arrival add queues behind them in the CU's memory pipe, so their NUMBER is
+            // on the signal's path.  Four neighbouring gate threads (units 4q .. 4q+3 of one batch row: adjacent lanes, 16
+            // contiguous bytes of the ring) hand their values to the first of them, which issues ONE 16-byte write-through
+            // store per gate and ONE 16-byte canary store into the next slot: 6 store instructions of a quarter of the
+            // lanes instead of 6 of all of them.  (UNITS and H are multiples of 4, so quads never straddle anything.)
+            float q[3][4];
+#define DS2_QUAD_BCAST(J)                                                                                              \
+    q[0][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_r), (J) * 0x55, 0xF, 0xF, true));         \
+    q[1][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_z), (J) * 0x55, 0xF, 0xF, true));         \
+    q[2][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_g), (J) * 0x55, 0xF, 0xF, true));
+            DS2_QUAD_BCAST(0)
+            DS2_QUAD_BCAST(1)
+            DS2_QUAD_BCAST(2)
+            DS2_QUAD_BCAST(3)
+#undef DS2_QUAD_BCAST
+            if (gate_ok && (jj & 3) == 0) {
+                const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, NSLOT * slot_floats * 4,
+                                                                                      0x00020000);
+                const int sbase = scur * slot_floats, nbase = (scur == NSLOT - 1 ? 0 : scur + 1) * slot_floats;
+                const int hos[3] = {ho0, ho1, ho2};
+                const u32x4 can4 = {CANARY_BITS, CANARY_BITS, CANARY_BITS, CANARY_BITS};
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {
+                    const f32x4 v = {q[g3][0], q[g3][1], q[g3][2], q[g3][3]};
+                    store_sc1_b128(rs_w, (sbase + hos[g3]) * 4, __builtin_bit_cast(u32x4, v));
+                    store_sc1_b128(rs_w, (nbase + hos[g3]) * 4, can4);
+                }
+            }
+        }
         DS2_TICK(5);
-        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sprev = scur;
+        scur = scur == NSLOT - 1 ? 0 : scur + 1;
         DS2_TICK(6);
         __syncthreads();
         DS2_TICK(7);
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
-        if (tid == 0 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
+        if (tid == SIGW * 64 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
             G[gbase] = sv_r;
@@ -784,8 +891,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             G[gbase + 2 * H] = sv_n;
             ghn[row * H + gj] = sv_g;
         }
+        // the drain, AFTER the signal: this step's stores (payload, next slot's canaries) are complete before the next
+        // step's arrival add -- and before its early loads are issued, so the wait never covers a fresh HBM load.  The
+        // polling wave (0) starts polling at once instead and drains after its poll has matched (its stores are old by then).
+        if (CAN && wave != SIGW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (tid == 0) leave_kernel(sync);
+    if (tid == SIGW * 64) leave_kernel(sync);   // the thread whose arrival adds must have been performed first
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -817,7 +928,7 @@ __device__ __forceinline__ float dpp_quad_add(float v) {   // Q = quad_perm sele
 // groups (gate-major: rgi = gate * 2 P + unit group) are dealt, four at a time, to "A sets" (CBSZ = 2) and a last pair to
 // a "B set" (CBSZ = 1) when 6 P is not a multiple of 4:  P = 1: (r0 r1 z0 z1) + (n0 n1);  P = 2: (r0-3) (z0-3) (n0-3);
 // P = 3: (r0-3) (r4 r5 z0 z1) (z2-5) (n0-3) + (n4 n5).
-template <int NGI, int P, int NBT>
+template <int NGI, int P, int NBT, bool CAN>
 __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        float* __restrict__ hout,
                                                                        const float* __restrict__ w_hh,
@@ -846,7 +957,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     const int ncg = (nb + 3) >> 2;
     const int ng = (H + 63) >> 6;
     const int slot_floats = ng * 64 * nb;
-    float* my_ring = ring + (size_t)(dir * P + bpart) * 2 * ((size_t)ng * 64 * bper);
+    constexpr int NSLOT = CAN ? 3 : 2;
+    float* my_ring = ring + (size_t)(dir * P + bpart) * NSLOT * ((size_t)ng * 64 * bper);
     if (tid == 0) abort_flag = 0;
 
     // resident weights (B operands): set A a, block q = row group 4 a + q; set B: block q = pair q >> 1, row group 4 NA + (q & 1)
@@ -884,32 +996,58 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     for (int bt = 0; bt < NBT; ++bt) hp[bt] = 0.f;
     unsigned int* shards = &sync->arrive[dir][bpart][0][0];
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    // this gate thread's position inside a ring slot, per batch pass (only gpart 0 stores)
+    int hoff[NBT];
+#pragma unroll
+    for (int bt = 0; bt < NBT; ++bt) {
+        const int lb = bt * RPP + nn;
+        const int rows4 = min(4, nb - (lb & ~3)) * 4;
+        hoff[bt] = (nn < RPP && lb < nb && gj < H && gpart == 0)
+                       ? (lb >> 2) * ng * 256 + (gj >> 2) * rows4 + (lb & 3) * 4 + (gj & 3) : -1;
+        if (CAN && hoff[bt] >= 0) store_canary(my_ring + hoff[bt]);          // slot 0 may hold an earlier launch's payload
+    }
+    if (CAN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int scur = 0, sprev = NSLOT - 1;                    // slot written this step / read this step (= last step's)
 
     for (int s = 0; s < T; ++s) {
         const int t = dir == 0 ? s : T - 1 - s;
         float gi_r[NBT], gi_z[NBT], gi_n[NBT], sv_a[NBT], sv_g[NBT], sv_h[NBT];
+        auto early_loads = [&]() {                      // independent of h: issued before the wait
 #pragma unroll
-        for (int bt = 0; bt < NBT; ++bt) {              // independent of h: issue before the wait
-            const int lb = bt * RPP + nn;
-            gi_r[bt] = gi_z[bt] = gi_n[bt] = sv_a[bt] = sv_g[bt] = sv_h[bt] = 0.f;
-            if (nn < RPP && lb < nb && gj < H) {
-                const size_t gbase = (((size_t)t * B + b0 + lb) * 2 + dir) * 3 * H + gj;
-                gi_r[bt] = G[gbase];
-                gi_z[bt] = G[gbase + H];
-                gi_n[bt] = G[gbase + 2 * H];
+            for (int bt = 0; bt < NBT; ++bt) {
+                const int lb = bt * RPP + nn;
+                gi_r[bt] = gi_z[bt] = gi_n[bt] = sv_a[bt] = sv_g[bt] = sv_h[bt] = 0.f;
+                if (nn < RPP && lb < nb && gj < H) {
+                    const size_t gbase = (((size_t)t * B + b0 + lb) * 2 + dir) * 3 * H + gj;
+                    gi_r[bt] = G[gbase];
+                    gi_z[bt] = G[gbase + H];
+                    gi_n[bt] = G[gbase + 2 * H];
+                }
             }
-        }
+        };
+        // signal-first: the polling wave polls first, drains its (old) stores, then issues these loads (see the backward
+        // kernel): a vmcnt wait must never sit behind freshly issued HBM loads
+        const bool poll_first = CAN && wave == 0 && s > 0;
+        if (!poll_first) early_loads();
         if (s > 0) {
             if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
+            if (poll_first) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
+                early_loads();
+            }
             __syncthreads();
             if (abort_flag) return;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-                my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
+                my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
             auto chunk = [&](int c, auto nci_tag) {
                 constexpr int NCI = decltype(nci_tag)::value;
                 f32x4 bf[NCI][NGI];
+                f32x4 accA[NA][NCI][2], accB[NBS > 0 ? NBS : 1][NCI][2];
+                unsigned long long t_retry = 0;
+              for (;;) {
+                asm volatile("" ::: "memory");                    // a retry must issue the loads again
 #pragma unroll
                 for (int gi = 0; gi < NGI; ++gi)
 #pragma unroll
@@ -925,7 +1063,6 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                     }
                 __builtin_amdgcn_sched_barrier(0);                 // every load out before the first MFMA
                 // two chains per set and quad (e parity): a wave needs ~12 independent chains to issue every 10 cycles
-                f32x4 accA[NA][NCI][2], accB[NBS > 0 ? NBS : 1][NCI][2];
 #pragma unroll
                 for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
@@ -956,6 +1093,20 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
 #undef DS2_FWD4_MFMA_A
 #undef DS2_FWD4_MFMA_B
                     }
+                if (!CAN) break;
+                bool stale = false;                                // a fragment whose payload had not landed yet?
+#pragma unroll
+                for (int gi = 0; gi < NGI; ++gi)
+#pragma unroll
+                    for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][gi]);
+                if (!__any(stale)) break;
+                DS2_RETRY();
+                if (t_retry == 0) t_retry = __builtin_amdgcn_s_memrealtime();
+                if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {
+                    if (lane == 0) __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+              }
                 // D register i = batch row i of the quad; lane (g, q, li): set A a -> gate row 4 (4 a + q) + li, k
                 // sub-index g; set B -> gate row 4 (4 NA + (q & 1)) + li, k sub-indices (g, q >> 1): one DPP add folds
                 // the two pairs
@@ -1017,16 +1168,17 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 const float h = (1.f - z) * n + z * hp[bt];
                 hp[bt] = h;
                 if (gpart == 0) {
-                    const int rows4 = min(4, nb - (lb & ~3)) * 4;
-                    store_sc1(&my_ring[(size_t)(s & 1) * slot_floats + (size_t)(lb >> 2) * ng * 256 + (gj >> 2) * rows4 +
-                                       (lb & 3) * 4 + (gj & 3)], h);
+                    store_sc1(my_ring + (size_t)scur * slot_floats + hoff[bt], h);
+                    if (CAN) store_canary(my_ring + (size_t)(scur == NSLOT - 1 ? 0 : scur + 1) * slot_floats + hoff[bt]);
                 }
                 sv_h[bt] = h;
                 sv_a[bt] = gpart == 1 ? r : (gpart == 2 ? z : n);
                 sv_g[bt] = gh_n;
             }
         }
-        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
+        if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
+        sprev = scur;
+        scur = scur == NSLOT - 1 ? 0 : scur + 1;
         __syncthreads();
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
         if (tid == 0 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
@@ -1045,6 +1197,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 }
             }
         }
+        // the drain, AFTER the signal (see CANARY_BITS): before the next step's arrival add and its early loads; the polling
+        // wave drains after its poll instead
+        if (CAN && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (tid == 0) leave_kernel(sync);
 }
@@ -1122,7 +1277,7 @@ bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float*
     return false;
 }
 
-template <int P, int NBT>
+template <int P, int NBT, bool CAN>
 bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
                             int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3};
@@ -1133,11 +1288,11 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
 #define DS2_FWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, P, NBT>),           \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, P, NBT, CAN>),           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
-        if (!grid_is_coresident(&gru_fwd_persistent4_kernel<K, P, NBT>, grid, lds)) return false;                \
-        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, P, NBT>), grid, block, lds, st, G, ghn, hout, w_hh, sync,    \
+        if (!grid_is_coresident(&gru_fwd_persistent4_kernel<K, P, NBT, CAN>, grid, lds)) return false;                \
+        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, P, NBT, CAN>), grid, block, lds, st, G, ghn, hout, w_hh, sync,    \
                            ring, T, B, H, dbg);                                                                  \
         return true;
     switch (ngi) {
@@ -1149,7 +1304,7 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
     return false;
 }
 
-template <int NRG>
+template <int NRG, bool CAN>
 bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                             SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3, 5};
@@ -1161,11 +1316,11 @@ bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float
 #define DS2_BWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K, NRG>),              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K, NRG, CAN>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
-        if (!grid_is_coresident(&gru_bwd_persistent4_kernel<K, NRG>, grid, lds)) return false;                   \
-        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K, NRG>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t,    \
+        if (!grid_is_coresident(&gru_bwd_persistent4_kernel<K, NRG, CAN>, grid, lds)) return false;                   \
+        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K, NRG, CAN>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t,    \
                            sync, ring, T, B, H, dbg);                                                            \
         return true;
     switch (ngi) {
@@ -1229,6 +1384,12 @@ inline bool persistent_ok(int B, int H) {
            (ds2_cdiv(3 * H / 16, NWP) <= 19) && (ds2_cdiv(H / 16, NWP) <= 7);
 }
 
+// DS2_GRU_SIGNAL_FIRST = 0 selects the drained hand-off (A/B timing); default: signal first, drain later (see CANARY_BITS)
+inline bool signal_first_protocol() {
+    const char* e = getenv("DS2_GRU_SIGNAL_FIRST");
+    return !(e && e[0] == '0');
+}
+
 inline size_t header_bytes() { return ((sizeof(SyncWs) + 255) / 256) * 256; }
 
 // diagnostics (results are WRONG when set): DS2_GRU_DBG bit0 = do not wait for arrivals, bit1 = skip the h loads +
@@ -1253,7 +1414,7 @@ inline size_t ring_floats(int B, int H) {
     const size_t a = (size_t)ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256;          // 16x16x4 forms
     const size_t b2 = (size_t)2 * ds2_cdiv(B, 2), b3 = (size_t)3 * ds2_cdiv(B, 3);
     const size_t b = (b2 > b3 ? b2 : b3) * (size_t)ds2_cdiv(3 * H, 64) * 64;          // 4x4x1 forms (1-3 batch parts)
-    return (size_t)2 * 2 * (a > b ? a : b);
+    return (size_t)2 * (2 * a > 3 * b ? 2 * a : 3 * b);                              // two slots / three (signal-first protocol)
 }
 
 extern "C" size_t ds2_gru_sync_ws_bytes(int B, int H) { return header_bytes() + ring_floats(B, H) * sizeof(float); }
@@ -1299,12 +1460,14 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     const bool use4 = (form ? form[0] == '4' : B <= 12) && fits4;
     if (use4) {
         const bool two = bper > rpp;
-        if (parts == 1) ok = two ? launch_fwd_persistent4<1, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
-                                 : launch_fwd_persistent4<1, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
-        else if (parts == 2) ok = two ? launch_fwd_persistent4<2, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
-                                      : launch_fwd_persistent4<2, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
-        else ok = two ? launch_fwd_persistent4<3, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
-                      : launch_fwd_persistent4<3, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+#define DS2_FWD4_GO(P_, N_)                                                                                         \
+    (can ? launch_fwd_persistent4<P_, N_, true>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)                    \
+         : launch_fwd_persistent4<P_, N_, false>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
+        const bool can = signal_first_protocol();
+        if (parts == 1) ok = two ? DS2_FWD4_GO(1, 2) : DS2_FWD4_GO(1, 1);
+        else if (parts == 2) ok = two ? DS2_FWD4_GO(2, 2) : DS2_FWD4_GO(2, 1);
+        else ok = two ? DS2_FWD4_GO(3, 2) : DS2_FWD4_GO(3, 1);
+#undef DS2_FWD4_GO
     }
     else if ((getenv("DS2_GRU_FWD_P2") ? getenv("DS2_GRU_FWD_P2")[0] == '1' : B >= 17) && B >= 2 && H % 16 == 0)
         ok = (B + 1) / 2 <= 16 ? launch_fwd_persistent_p2<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
@@ -1354,12 +1517,13 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
         if (split && split[0] >= '1' && split[0] <= '3' && (split[0] - '0') <= B) parts = split[0] - '0';
     }
     const bool ngi_ok = ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5;
-    if (use4 && ngi_ok && parts == 3)
-        ok = launch_bwd_persistent4<6>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-    else if (use4 && ngi_ok && parts == 2)
-        ok = launch_bwd_persistent4<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-    else if (use4 && ngi_ok)
-        ok = launch_bwd_persistent4<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+#define DS2_BWD4_GO(R_)                                                                                             \
+    (signal_first_protocol()                                                                                         \
+         ? launch_bwd_persistent4<R_, true>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)               \
+         : launch_bwd_persistent4<R_, false>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
+    if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
+    else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
+    else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);
     else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);

@@ -56,3 +56,13 @@ if __name__ == '__main__':
             os.environ['DS2_GRU_DBG'] = str(dbg)
             f, b = measure(bsz)
             print('B=%2d DBG=%d  fwd %.2f us/step  bwd %.2f us/step' % (bsz, dbg, f, b), flush=True)
+    if variant == 'timing':
+        import ctypes
+        try:
+            fn = lib.load().ds2_debug_read_retries
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            buf = ctypes.c_uint(0)
+            fn(ctypes.byref(buf), 1)
+            print('signal-first protocol: %d fragment re-loads in this process' % buf.value)
+        except AttributeError:
+            pass
