@@ -111,4 +111,8 @@ if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))
     if '--variant' in sys.argv:
         name = sys.argv[sys.argv.index('--variant') + 1]
-        print(build_variant(name, {'timing': ['-DDS2_TIMING=1']}[name]))
+        flags = {'timing': ['-DDS2_TIMING=1']}.get(name)
+        if flags is None:                      # e.g. --variant spec_12_4 -> -DDS2_SPEC_DELAY=12 -DDS2_SPEC_BACKOFF=4
+            _, d, b = name.split('_')
+            flags = ['-DDS2_SPEC_DELAY=%s' % d, '-DDS2_SPEC_BACKOFF=%s' % b]
+        print(build_variant(name, flags))

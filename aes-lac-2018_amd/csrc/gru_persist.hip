@@ -1,6 +1,7 @@
 // Persistent BiGRU recurrence kernels for gfx950 (one launch per layer pass).
 #include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <type_traits>
@@ -618,13 +619,13 @@ constexpr int RED4_PITCH = NWP * 4 + 4;   // floats per reduced value in LDS: 32
 // per step and waits for 50 / 34 producers instead of 100.  The launcher picks the form with a cost model fitted to
 // measurements: a step costs ~0.40 us per (batch quad x 8 units) of MFMA + fold work and ~0.34 us per 4 batch rows
 // of hand-off loads per workgroup.
-template <int NGI, int NRG, bool CAN>
+template <int NGI, int NRG, int PROTO>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        const float* __restrict__ hout,
                                                                        const float* __restrict__ d_out,
                                                                        const float* __restrict__ w_hh_t,
                                                                        SyncWs* __restrict__ sync, float* __restrict__ ring,
-                                                                       int T, int B, int H, int dbg) {
+                                                                       int T, int B, int H, int dbg, int spec) {
     // [value = (rg, cg, r 4, j 4)][RED4_PITCH: partial = wave * 4 + lane row]: a gate thread's 32 partials are
     // contiguous (eight ds_read_b128 in flight; as 32 scalar reads the compiler chained read -> wait -> add, ~0.6 us
     // per step), and the pitch of 36 puts the 16 storing lanes of a fold (4 rows x 4 j) on 16 different banks
@@ -646,7 +647,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     const int ncg = (nb + 3) >> 2;
     const int ng = (K + 63) >> 6;                       // 64-wide k groups
     const int slot_floats = ng * 64 * nb;               // a partial last quad keeps only its nb & 3 rows
-    constexpr int NSLOT = CAN ? 3 : 2;
+    // PROTO 0: drained hand-off; 1: signal first, drain later; 2: speculative loads, no per-step counters (see CANARY_BITS)
+    constexpr bool CAN = PROTO >= 1, SPEC = PROTO == 2;
+    constexpr int NSLOT = SPEC ? 4 : (CAN ? 3 : 2);
+    constexpr int CAHEAD = SPEC ? 2 : 1;                // the canary goes this many slots ahead of the payload
     // the wave that signals and polls: with the signal-first protocol the LAST wave, which has few or no gate threads (96 of
     // them in waves 0-1 at B = 10), so its arrival add does not queue behind its own hand-off stores
     constexpr int SIGW = CAN ? NWP - 1 : 0;
@@ -679,14 +683,27 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     const int hoff = (nn >> 2) * ng * 256 + (nn & 3) * 4;
     const int ho0 = hoff + (gj >> 2) * rows4g + (gj & 3), ho1 = hoff + ((H + gj) >> 2) * rows4g + ((H + gj) & 3),
               ho2 = hoff + ((2 * H + gj) >> 2) * rows4g + ((2 * H + gj) & 3);
-    if (CAN && gate_ok) {                               // slot 0 may hold an earlier launch's payload
-        store_canary(my_ring + ho0);
-        store_canary(my_ring + ho1);
-        store_canary(my_ring + ho2);
+    if (CAN && gate_ok) {                               // slot 0 (and 1) may hold an earlier launch's payload
+#pragma unroll
+        for (int sl = 0; sl < CAHEAD; ++sl) {
+            store_canary(my_ring + (size_t)sl * slot_floats + ho0);
+            store_canary(my_ring + (size_t)sl * slot_floats + ho1);
+            store_canary(my_ring + (size_t)sl * slot_floats + ho2);
+        }
     }
     if (CAN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (SPEC) {
+        // The speculative protocol has no per-step counters, so nothing in a step tells a consumer that a producer has even
+        // started: ONE counted rendezvous per launch makes sure every workgroup of the group has put its canaries into the
+        // first slots before anybody reads them.
+        if (tid == SIGW * 64) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == SIGW && !wait_arrivals(shards, 1, nslice, lane, &sync->error) && lane == 0) abort_flag = 1;
+        __syncthreads();
+        if (abort_flag) return;
+    }
     int scur = 0, sprev = NSLOT - 1;                    // slot written this step / read this step (= last step's)
+    int spec_delay = spec & 0xFF, spec_clean = 0;       // speculative protocol: see spec_timing()
 
     for (int s = 0; s < T; ++s) {
         DS2_TICK(0);
@@ -709,19 +726,21 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         };
         // signal-first: the polling wave polls FIRST, then waits for its own (by then old) stores, and only then issues
         // these loads -- a vmcnt wait behind freshly issued HBM loads would put their latency on the step's chain
-        const bool poll_first = CAN && wave == SIGW && s > 0;
+        const bool poll_first = CAN && !SPEC && wave == SIGW && s > 0;
         if (!poll_first) early_loads();
         if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == SIGW && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
-                abort_flag = 1;
-            if (poll_first) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
-                early_loads();
+            if (!SPEC) {
+                if (!DS2_DBG(dbg, 1) && wave == SIGW && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+                    abort_flag = 1;
+                if (poll_first) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
+                    early_loads();
+                }
+                DS2_TICK(1);
+                __syncthreads();
+                DS2_TICK(2);
+                if (abort_flag) return;
             }
-            DS2_TICK(1);
-            __syncthreads();
-            DS2_TICK(2);
-            if (abort_flag) return;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
                 my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
             auto chunk = [&](int c, auto nci_tag) {
@@ -729,6 +748,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 f32x4 bf[NCI][NGI];
                 f32x4 acc[NRG][NCI];
                 unsigned long long t_retry = 0;
+              bool retried = false;
+              if (SPEC)
+                  for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
               for (;;) {
                 asm volatile("" ::: "memory");                    // a retry must issue the loads again
 #pragma unroll
@@ -769,11 +791,26 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                     for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][gi]);
                 if (!__any(stale)) break;
                 DS2_RETRY();
+                retried = true;
+                if (SPEC)
+                    for (int i = 0; i < ((spec >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);
                 if (t_retry == 0) t_retry = __builtin_amdgcn_s_memrealtime();
-                if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {
-                    if (lane == 0) __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {   // a payload never came: flag it, leave the launch
+                    if (lane == 0) {
+                        __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        abort_flag = 1;
+                    }
                     break;
                 }
+              }
+              if (SPEC && (spec >> 16)) {      // adaptive first-attempt delay: +2 after a failed attempt, -1 after 8 clean steps
+                  if (retried) {
+                      spec_delay = min(spec_delay + 2, 63);
+                      spec_clean = 0;
+                  } else if (++spec_clean == 8) {
+                      spec_clean = 0;
+                      spec_delay = max(spec_delay - 1, 0);
+                  }
               }
                 // fold the 16 per-block partials: two DPP adds leave each 16-lane row's sum in its lanes 12..15
                 // (all the DPP adds first, as independent chains, then ONE predicated region with the stores: written value
@@ -820,6 +857,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         DS2_TICK(3);
         __syncthreads();
         DS2_TICK(4);
+        if (CAN && abort_flag) return;                  // a wave gave up on a payload that never came (bounded re-loads)
         if (gate_ok) {
             if (s > 0) {
                 const int rg = jj >> 2, rr = jj & 3, cg = nn >> 2, bj = nn & 3;
@@ -861,16 +899,22 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             DS2_QUAD_BCAST(2)
             DS2_QUAD_BCAST(3)
 #undef DS2_QUAD_BCAST
+            // speculative protocol: the stores of the PREVIOUS step (a step old) are complete before this step's payload goes
+            // out -- a consumer that has seen this payload can rely on every canary this workgroup wrote before it
+            if (SPEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (gate_ok && (jj & 3) == 0) {
                 const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, NSLOT * slot_floats * 4,
                                                                                       0x00020000);
-                const int sbase = scur * slot_floats, nbase = (scur == NSLOT - 1 ? 0 : scur + 1) * slot_floats;
+                const int sbase = scur * slot_floats, nbase = ((scur + CAHEAD) % NSLOT) * slot_floats;
                 const int hos[3] = {ho0, ho1, ho2};
                 const u32x4 can4 = {CANARY_BITS, CANARY_BITS, CANARY_BITS, CANARY_BITS};
+                // (speculative protocol, fault-injection builds: workgroup 0 'loses' its payload of step 2 -> its consumers
+                // must time out on the canary, not hang)
+                const bool lose = SPEC && DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
 #pragma unroll
                 for (int g3 = 0; g3 < 3; ++g3) {
                     const f32x4 v = {q[g3][0], q[g3][1], q[g3][2], q[g3][3]};
-                    store_sc1_b128(rs_w, (sbase + hos[g3]) * 4, __builtin_bit_cast(u32x4, v));
+                    if (!lose) store_sc1_b128(rs_w, (sbase + hos[g3]) * 4, __builtin_bit_cast(u32x4, v));
                     store_sc1_b128(rs_w, (nbase + hos[g3]) * 4, can4);
                 }
             }
@@ -883,7 +927,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         __syncthreads();
         DS2_TICK(7);
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
-        if (tid == SIGW * 64 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
+        if (!SPEC && tid == SIGW * 64 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
             G[gbase] = sv_r;
@@ -894,7 +938,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         // the drain, AFTER the signal: this step's stores (payload, next slot's canaries) are complete before the next
         // step's arrival add -- and before its early loads are issued, so the wait never covers a fresh HBM load.  The
         // polling wave (0) starts polling at once instead and drains after its poll has matched (its stores are old by then).
-        if (CAN && wave != SIGW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (CAN && !SPEC && wave != SIGW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (tid == SIGW * 64) leave_kernel(sync);   // the thread whose arrival adds must have been performed first
 }
@@ -928,12 +972,12 @@ __device__ __forceinline__ float dpp_quad_add(float v) {   // Q = quad_perm sele
 // groups (gate-major: rgi = gate * 2 P + unit group) are dealt, four at a time, to "A sets" (CBSZ = 2) and a last pair to
 // a "B set" (CBSZ = 1) when 6 P is not a multiple of 4:  P = 1: (r0 r1 z0 z1) + (n0 n1);  P = 2: (r0-3) (z0-3) (n0-3);
 // P = 3: (r0-3) (r4 r5 z0 z1) (z2-5) (n0-3) + (n4 n5).
-template <int NGI, int P, int NBT, bool CAN>
+template <int NGI, int P, int NBT, int PROTO>
 __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        float* __restrict__ hout,
                                                                        const float* __restrict__ w_hh,
                                                                        SyncWs* __restrict__ sync, float* __restrict__ ring,
-                                                                       int T, int B, int H, int dbg) {
+                                                                       int T, int B, int H, int dbg, int spec) {
     // [local batch row][gate row = gate * UNITS + unit][FWD4_PITCH partials]
     extern __shared__ __attribute__((aligned(16))) float red4[];
     __shared__ int abort_flag;
@@ -957,7 +1001,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     const int ncg = (nb + 3) >> 2;
     const int ng = (H + 63) >> 6;
     const int slot_floats = ng * 64 * nb;
-    constexpr int NSLOT = CAN ? 3 : 2;
+    constexpr bool CAN = PROTO >= 1, SPEC = PROTO == 2;       // protocols: see the backward kernel and CANARY_BITS
+    constexpr int NSLOT = SPEC ? 4 : (CAN ? 3 : 2);
+    constexpr int CAHEAD = SPEC ? 2 : 1;
     float* my_ring = ring + (size_t)(dir * P + bpart) * NSLOT * ((size_t)ng * 64 * bper);
     if (tid == 0) abort_flag = 0;
 
@@ -1004,11 +1050,21 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         const int rows4 = min(4, nb - (lb & ~3)) * 4;
         hoff[bt] = (nn < RPP && lb < nb && gj < H && gpart == 0)
                        ? (lb >> 2) * ng * 256 + (gj >> 2) * rows4 + (lb & 3) * 4 + (gj & 3) : -1;
-        if (CAN && hoff[bt] >= 0) store_canary(my_ring + hoff[bt]);          // slot 0 may hold an earlier launch's payload
+        if (CAN && hoff[bt] >= 0) {                     // slot 0 (and 1) may hold an earlier launch's payload
+#pragma unroll
+            for (int sl = 0; sl < CAHEAD; ++sl) store_canary(my_ring + (size_t)sl * slot_floats + hoff[bt]);
+        }
     }
     if (CAN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (SPEC) {   // one counted rendezvous per launch: every producer's start-up canaries are in place before anybody reads
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0 && !wait_arrivals(shards, 1, nslice, lane, &sync->error) && lane == 0) abort_flag = 1;
+        __syncthreads();
+        if (abort_flag) return;
+    }
     int scur = 0, sprev = NSLOT - 1;                    // slot written this step / read this step (= last step's)
+    int spec_delay = spec & 0xFF, spec_clean = 0;       // speculative protocol: see spec_timing()
 
     for (int s = 0; s < T; ++s) {
         const int t = dir == 0 ? s : T - 1 - s;
@@ -1028,17 +1084,19 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         };
         // signal-first: the polling wave polls first, drains its (old) stores, then issues these loads (see the backward
         // kernel): a vmcnt wait must never sit behind freshly issued HBM loads
-        const bool poll_first = CAN && wave == 0 && s > 0;
+        const bool poll_first = CAN && !SPEC && wave == 0 && s > 0;
         if (!poll_first) early_loads();
         if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
-                abort_flag = 1;
-            if (poll_first) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
-                early_loads();
+            if (!SPEC) {
+                if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+                    abort_flag = 1;
+                if (poll_first) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
+                    early_loads();
+                }
+                __syncthreads();
+                if (abort_flag) return;
             }
-            __syncthreads();
-            if (abort_flag) return;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
                 my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
             auto chunk = [&](int c, auto nci_tag) {
@@ -1046,6 +1104,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 f32x4 bf[NCI][NGI];
                 f32x4 accA[NA][NCI][2], accB[NBS > 0 ? NBS : 1][NCI][2];
                 unsigned long long t_retry = 0;
+              bool retried = false;
+              if (SPEC)
+                  for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
               for (;;) {
                 asm volatile("" ::: "memory");                    // a retry must issue the loads again
 #pragma unroll
@@ -1101,11 +1162,26 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                     for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][gi]);
                 if (!__any(stale)) break;
                 DS2_RETRY();
+                retried = true;
+                if (SPEC)
+                    for (int i = 0; i < ((spec >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);
                 if (t_retry == 0) t_retry = __builtin_amdgcn_s_memrealtime();
-                if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {
-                    if (lane == 0) __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {   // a payload never came: flag it, leave the launch
+                    if (lane == 0) {
+                        __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        abort_flag = 1;
+                    }
                     break;
                 }
+              }
+              if (SPEC && (spec >> 16)) {      // adaptive first-attempt delay: +2 after a failed attempt, -1 after 8 clean steps
+                  if (retried) {
+                      spec_delay = min(spec_delay + 2, 63);
+                      spec_clean = 0;
+                  } else if (++spec_clean == 8) {
+                      spec_clean = 0;
+                      spec_delay = max(spec_delay - 1, 0);
+                  }
               }
                 // D register i = batch row i of the quad; lane (g, q, li): set A a -> gate row 4 (4 a + q) + li, k
                 // sub-index g; set B -> gate row 4 (4 NA + (q & 1)) + li, k sub-indices (g, q >> 1): one DPP add folds
@@ -1141,6 +1217,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
             }
         }
         __syncthreads();
+        if (CAN && abort_flag) return;                  // a wave gave up on a payload that never came (bounded re-loads)
+        // speculative protocol: the previous step's stores (a step old) are complete before this step's payload goes out
+        if (SPEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {
             const int lb = bt * RPP + nn;
@@ -1168,8 +1247,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 const float h = (1.f - z) * n + z * hp[bt];
                 hp[bt] = h;
                 if (gpart == 0) {
-                    store_sc1(my_ring + (size_t)scur * slot_floats + hoff[bt], h);
-                    if (CAN) store_canary(my_ring + (size_t)(scur == NSLOT - 1 ? 0 : scur + 1) * slot_floats + hoff[bt]);
+                    // (speculative protocol, fault-injection builds: workgroup 0 'loses' its payload of step 2)
+                    const bool lose = SPEC && DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
+                    if (!lose) store_sc1(my_ring + (size_t)scur * slot_floats + hoff[bt], h);
+                    if (CAN) store_canary(my_ring + (size_t)((scur + CAHEAD) % NSLOT) * slot_floats + hoff[bt]);
                 }
                 sv_h[bt] = h;
                 sv_a[bt] = gpart == 1 ? r : (gpart == 2 ? z : n);
@@ -1181,7 +1262,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         scur = scur == NSLOT - 1 ? 0 : scur + 1;
         __syncthreads();
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
-        if (tid == 0 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
+        if (!SPEC && tid == 0 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {   // saved activations: read by later launches only, off the critical path
@@ -1199,9 +1280,27 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         }
         // the drain, AFTER the signal (see CANARY_BITS): before the next step's arrival add and its early loads; the polling
         // wave drains after its poll instead
-        if (CAN && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (CAN && !SPEC && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (tid == 0) leave_kernel(sync);
+}
+
+// Speculative protocol: how long a wave waits (units of s_sleep 1 = 64 clocks) before a step's first hand-off loads, and
+// between re-loads.  A failed attempt costs a full round trip and adds polling traffic from 1600 waves, so the first attempt
+// is timed to land just after the slowest producer's payload; measured optimum (tools/gru_sweep.py, B = 4 .. 12): the forward
+// kernel 8-12, the backward kernel (more and wider stores per producer) ~20.  DS2_GRU_SPEC_FWD / _BWD = "delay,backoff".
+inline int spec_timing(int bwd) {
+    int delay = bwd ? 14 : 10, backoff = 2;
+    const char* e = getenv(bwd ? "DS2_GRU_SPEC_BWD" : "DS2_GRU_SPEC_FWD");
+    if (e) {
+        delay = atoi(e);
+        const char* c = strchr(e, ',');
+        if (c) backoff = atoi(c + 1);
+    }
+    int adaptive = 1;
+    const char* a = getenv("DS2_GRU_SPEC_ADAPT");
+    if (a) adaptive = atoi(a);
+    return (delay & 0xFF) | ((backoff & 0xFF) << 8) | (adaptive << 16);
 }
 
 inline int pick_kbw(int need, const int* opts, int nopts) {
@@ -1277,7 +1376,7 @@ bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float*
     return false;
 }
 
-template <int P, int NBT, bool CAN>
+template <int P, int NBT, int PROTO>
 bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
                             int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3};
@@ -1288,12 +1387,12 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
 #define DS2_FWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, P, NBT, CAN>),           \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, P, NBT, PROTO>),           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
-        if (!grid_is_coresident(&gru_fwd_persistent4_kernel<K, P, NBT, CAN>, grid, lds)) return false;                \
-        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, P, NBT, CAN>), grid, block, lds, st, G, ghn, hout, w_hh, sync,    \
-                           ring, T, B, H, dbg);                                                                  \
+        if (!grid_is_coresident(&gru_fwd_persistent4_kernel<K, P, NBT, PROTO>, grid, lds)) return false;                \
+        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, P, NBT, PROTO>), grid, block, lds, st, G, ghn, hout, w_hh, sync,    \
+                           ring, T, B, H, dbg, spec_timing(0));                                                                  \
         return true;
     switch (ngi) {
         DS2_FWD4_CASE(1)
@@ -1304,7 +1403,7 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
     return false;
 }
 
-template <int NRG, bool CAN>
+template <int NRG, int PROTO>
 bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                             SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3, 5};
@@ -1316,12 +1415,12 @@ bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float
 #define DS2_BWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K, NRG, CAN>),              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K, NRG, PROTO>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
-        if (!grid_is_coresident(&gru_bwd_persistent4_kernel<K, NRG, CAN>, grid, lds)) return false;                   \
-        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K, NRG, CAN>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t,    \
-                           sync, ring, T, B, H, dbg);                                                            \
+        if (!grid_is_coresident(&gru_bwd_persistent4_kernel<K, NRG, PROTO>, grid, lds)) return false;                   \
+        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K, NRG, PROTO>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t,    \
+                           sync, ring, T, B, H, dbg, spec_timing(1));                                                            \
         return true;
     switch (ngi) {
         DS2_BWD4_CASE(1)
@@ -1384,10 +1483,10 @@ inline bool persistent_ok(int B, int H) {
            (ds2_cdiv(3 * H / 16, NWP) <= 19) && (ds2_cdiv(H / 16, NWP) <= 7);
 }
 
-// DS2_GRU_SIGNAL_FIRST = 0 selects the drained hand-off (A/B timing); default: signal first, drain later (see CANARY_BITS)
-inline bool signal_first_protocol() {
-    const char* e = getenv("DS2_GRU_SIGNAL_FIRST");
-    return !(e && e[0] == '0');
+// DS2_GRU_PROTO = 0 drained hand-off, 1 signal first / drain later, 2 speculative loads (A/B timing); see CANARY_BITS
+inline int handoff_protocol() {
+    const char* e = getenv("DS2_GRU_PROTO");
+    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
 }
 
 inline size_t header_bytes() { return ((sizeof(SyncWs) + 255) / 256) * 256; }
@@ -1414,7 +1513,7 @@ inline size_t ring_floats(int B, int H) {
     const size_t a = (size_t)ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256;          // 16x16x4 forms
     const size_t b2 = (size_t)2 * ds2_cdiv(B, 2), b3 = (size_t)3 * ds2_cdiv(B, 3);
     const size_t b = (b2 > b3 ? b2 : b3) * (size_t)ds2_cdiv(3 * H, 64) * 64;          // 4x4x1 forms (1-3 batch parts)
-    return (size_t)2 * (2 * a > 3 * b ? 2 * a : 3 * b);                              // two slots / three (signal-first protocol)
+    return (size_t)2 * (2 * a > 4 * b ? 2 * a : 4 * b);                              // two slots / up to four (canary protocols)
 }
 
 extern "C" size_t ds2_gru_sync_ws_bytes(int B, int H) { return header_bytes() + ring_floats(B, H) * sizeof(float); }
@@ -1461,9 +1560,10 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     if (use4) {
         const bool two = bper > rpp;
 #define DS2_FWD4_GO(P_, N_)                                                                                         \
-    (can ? launch_fwd_persistent4<P_, N_, true>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)                    \
-         : launch_fwd_persistent4<P_, N_, false>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
-        const bool can = signal_first_protocol();
+    (proto == 2 ? launch_fwd_persistent4<P_, N_, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)                \
+     : proto == 1 ? launch_fwd_persistent4<P_, N_, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)              \
+                  : launch_fwd_persistent4<P_, N_, 0>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
+        const int proto = handoff_protocol();
         if (parts == 1) ok = two ? DS2_FWD4_GO(1, 2) : DS2_FWD4_GO(1, 1);
         else if (parts == 2) ok = two ? DS2_FWD4_GO(2, 2) : DS2_FWD4_GO(2, 1);
         else ok = two ? DS2_FWD4_GO(3, 2) : DS2_FWD4_GO(3, 1);
@@ -1518,9 +1618,9 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     }
     const bool ngi_ok = ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5;
 #define DS2_BWD4_GO(R_)                                                                                             \
-    (signal_first_protocol()                                                                                         \
-         ? launch_bwd_persistent4<R_, true>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)               \
-         : launch_bwd_persistent4<R_, false>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
+    (handoff_protocol() == 2 ? launch_bwd_persistent4<R_, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st) \
+     : handoff_protocol() == 1 ? launch_bwd_persistent4<R_, 1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st) \
+                               : launch_bwd_persistent4<R_, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
     if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);
