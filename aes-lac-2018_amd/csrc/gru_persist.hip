@@ -132,6 +132,11 @@ __device__ __forceinline__ void store_canary(float* p) {
 __device__ __forceinline__ void store_sc1_b128(__amdgpu_buffer_rsrc_t rs, int byte_off, u32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16 /* sc1 */);
 }
+// a payload value must never look like the canary: a NaN with the all-ones payload (only reachable from NaN inputs carrying
+// that payload) is re-encoded as the canonical quiet NaN -- still a NaN for every consumer
+__device__ __forceinline__ float not_canary(float v) {
+    return __float_as_uint(v) == CANARY_BITS ? __uint_as_float(0x7FC00000u) : v;
+}
 __device__ __forceinline__ bool has_canary(f32x4 v) {
     const u32x4 u = __builtin_bit_cast(u32x4, v);
     return (u[0] == CANARY_BITS) | (u[1] == CANARY_BITS) | (u[2] == CANARY_BITS) | (u[3] == CANARY_BITS);
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 f32x4 acc[NRG][NCI];
                 unsigned long long t_retry = 0;
               bool retried = false;
-              if (SPEC)
+              if (SPEC && c == 0)                                  // before the step's FIRST hand-off loads only
                   for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
               for (;;) {
                 asm volatile("" ::: "memory");                    // a retry must issue the loads again
@@ -803,7 +808,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                     break;
                 }
               }
-              if (SPEC && (spec >> 16)) {      // adaptive first-attempt delay: +2 after a failed attempt, -1 after 8 clean steps
+              if (SPEC && (spec >> 16) && c == 0) {   // adaptive first-attempt delay: +2 after a failed attempt, -1 after 8 clean steps
                   if (retried) {
                       spec_delay = min(spec_delay + 2, 63);
                       spec_clean = 0;
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 const bool lose = SPEC && DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
 #pragma unroll
                 for (int g3 = 0; g3 < 3; ++g3) {
-                    const f32x4 v = {q[g3][0], q[g3][1], q[g3][2], q[g3][3]};
+                    const f32x4 v = {not_canary(q[g3][0]), not_canary(q[g3][1]), not_canary(q[g3][2]), not_canary(q[g3][3])};
                     if (!lose) store_sc1_b128(rs_w, (sbase + hos[g3]) * 4, __builtin_bit_cast(u32x4, v));
                     store_sc1_b128(rs_w, (nbase + hos[g3]) * 4, can4);
                 }
@@ -1105,7 +1110,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 f32x4 accA[NA][NCI][2], accB[NBS > 0 ? NBS : 1][NCI][2];
                 unsigned long long t_retry = 0;
               bool retried = false;
-              if (SPEC)
+              if (SPEC && c == 0)                                  // before the step's FIRST hand-off loads only
                   for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
               for (;;) {
                 asm volatile("" ::: "memory");                    // a retry must issue the loads again
@@ -1174,7 +1179,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                     break;
                 }
               }
-              if (SPEC && (spec >> 16)) {      // adaptive first-attempt delay: +2 after a failed attempt, -1 after 8 clean steps
+              if (SPEC && (spec >> 16) && c == 0) {   // adaptive first-attempt delay: +2 after a failed attempt, -1 after 8 clean steps
                   if (retried) {
                       spec_delay = min(spec_delay + 2, 63);
                       spec_clean = 0;
@@ -1249,7 +1254,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 if (gpart == 0) {
                     // (speculative protocol, fault-injection builds: workgroup 0 'loses' its payload of step 2)
                     const bool lose = SPEC && DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
-                    if (!lose) store_sc1(my_ring + (size_t)scur * slot_floats + hoff[bt], h);
+                    if (!lose) store_sc1(my_ring + (size_t)scur * slot_floats + hoff[bt], CAN ? not_canary(h) : h);
                     if (CAN) store_canary(my_ring + (size_t)((scur + CAHEAD) % NSLOT) * slot_floats + hoff[bt]);
                 }
                 sv_h[bt] = h;
@@ -1483,10 +1488,15 @@ inline bool persistent_ok(int B, int H) {
            (ds2_cdiv(3 * H / 16, NWP) <= 19) && (ds2_cdiv(H / 16, NWP) <= 7);
 }
 
-// DS2_GRU_PROTO = 0 drained hand-off, 1 signal first / drain later, 2 speculative loads (A/B timing); see CANARY_BITS
-inline int handoff_protocol() {
+// Hand-off protocol of the 4x4x1 forms: 0 drained, 1 signal first / drain later, 2 speculative loads (see CANARY_BITS).
+// Default by the batch rows a workgroup handles: ONE batch quad (<= 4 rows: B <= 12 with three parts) -> speculative
+// (B = 10: 3.45 -> 3.1 us per step, B = 8: 2.9 -> 2.5, B = 4: 2.5 -> 1.9); with more rows the step is MFMA / store bound, the
+// canaries double the write-through stores and the drained protocol is faster (B = 32 backward: 6.4 vs 6.8 us, B = 64:
+// 11.3 vs 12.8).  DS2_GRU_PROTO = 0 / 1 / 2 forces one (A/B timing).
+inline int handoff_protocol(int rows_per_part) {
     const char* e = getenv("DS2_GRU_PROTO");
-    return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+    if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
+    return rows_per_part <= 4 ? 2 : 0;
 }
 
 inline size_t header_bytes() { return ((sizeof(SyncWs) + 255) / 256) * 256; }
@@ -1563,7 +1573,7 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     (proto == 2 ? launch_fwd_persistent4<P_, N_, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)                \
      : proto == 1 ? launch_fwd_persistent4<P_, N_, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)              \
                   : launch_fwd_persistent4<P_, N_, 0>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
-        const int proto = handoff_protocol();
+        const int proto = handoff_protocol(bper);
         if (parts == 1) ok = two ? DS2_FWD4_GO(1, 2) : DS2_FWD4_GO(1, 1);
         else if (parts == 2) ok = two ? DS2_FWD4_GO(2, 2) : DS2_FWD4_GO(2, 1);
         else ok = two ? DS2_FWD4_GO(3, 2) : DS2_FWD4_GO(3, 1);
@@ -1617,10 +1627,11 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
         if (split && split[0] >= '1' && split[0] <= '3' && (split[0] - '0') <= B) parts = split[0] - '0';
     }
     const bool ngi_ok = ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5;
+    const int proto = handoff_protocol(ds2_cdiv(B, parts));
 #define DS2_BWD4_GO(R_)                                                                                             \
-    (handoff_protocol() == 2 ? launch_bwd_persistent4<R_, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st) \
-     : handoff_protocol() == 1 ? launch_bwd_persistent4<R_, 1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st) \
-                               : launch_bwd_persistent4<R_, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
+    (proto == 2 ? launch_bwd_persistent4<R_, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)           \
+     : proto == 1 ? launch_bwd_persistent4<R_, 1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)         \
+                  : launch_bwd_persistent4<R_, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
     if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);
