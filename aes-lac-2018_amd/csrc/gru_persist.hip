@@ -44,10 +44,10 @@ extern "C" int ds2_debug_read_retries(unsigned int* out, int reset) {
     }
     return 0;
 }
-#define DS2_RETRY() do { if (lane == 0) __hip_atomic_fetch_add(&ds2_retries, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#define DS2_RETRY_FLUSH(n) do { if ((threadIdx.x & 63) == 0 && (n)) __hip_atomic_fetch_add(&ds2_retries, (unsigned int)(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
 #define DS2_TICK(i) do {} while (0)
-#define DS2_RETRY() do {} while (0)
+#define DS2_RETRY_FLUSH(n) do {} while (0)
 #endif
 
 namespace {
@@ -114,15 +114,23 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
-// "Signal first, drain later" hand-off (4x4x1 forms, CAN = true).  In the drained protocol a step's chain is
-//   stores -> wait for their acks (~0.45 us) -> barrier -> arrival add -> (others) poll -> load,
-// four dependent memory operations.  Here the arrival add goes out right behind the stores and the wave waits for the
-// acks AFTERWARDS, while it would otherwise sit idle waiting for the other workgroups' arrivals.  A consumer may
-// therefore see the count before a payload has landed; to detect that, every ring position is overwritten with
-// CANARY_BITS (a NaN pattern no arithmetic produces) one step before its next payload, by the same lane (same address:
-// the two stores stay ordered), three slots deep, and a wave that finds the pattern in a fragment loads its fragments
-// again.  What the counter still guarantees: the canary of the slot has landed (each step's stores are drained before the
-// next step's arrival add), so the slot's three-steps-old payload can never be mistaken for the new one.
+// Speculative hand-off (4x4x1 forms, PROTO = 2; chosen when a workgroup handles one batch quad, i.e. B <= 12).
+// The counted protocol's step is a chain of four dependent memory operations -- payload stores -> their acks (the drain,
+// ~0.45 us) -> arrival add -> (others) poll -> payload loads -- about 2 us of every 3.45 us step at B = 10.  Here a step has
+// TWO: payload stores, payload loads.  There are no per-step counters, no drain before a signal and no poll: a consumer simply
+// loads the slot and checks that what it got is payload.  To make that check possible every ring position is overwritten
+// with CANARY_BITS (a NaN pattern arithmetic never produces; payload values that alias it are re-encoded) TWO steps before
+// its next payload, by the same lane (same address: the stores stay ordered), in a ring of FOUR slots; a wave that finds the
+// pattern in a fragment loads that fragment again (bounded by SPIN_TICKS).  Why a stale payload can never pass for a new
+// one: a workgroup waits for its previous step's stores (a step old, so the wait is free) before it issues a step's
+// payload, so a consumer that has seen producer P's payload of step s knows P's canaries of steps < s have landed -- and it
+// must have seen that payload to finish its own step s + 1, before it reads the slot of step s + 1, whose canary P wrote in
+// step s - 1.  One counted rendezvous per launch covers the start (slots 0 and 1 canaried by everyone before anyone reads).
+// A wave times its first attempt (an adaptive s_sleep count, +1 after a step with a re-load, -1 after four clean ones): a
+// failed attempt costs a round trip and, from 1600 waves, polling traffic.  Measured (H = 800, us per step fwd / bwd):
+// B = 10: 3.48 / 3.44 -> 3.1 / 3.1; B = 8: 2.90 / 2.93 -> 2.45 / 2.55; B = 4: 2.52 / 2.52 -> 1.9 / 2.1.
+// (A "signal first, drain later" variant -- canaries one slot ahead, counters kept, the drain moved behind the arrival add --
+// gained 3 %; it is gone.)
 constexpr unsigned int CANARY_BITS = 0xFFFFFFFFu;
 __device__ __forceinline__ void store_canary(float* p) {
     __hip_atomic_store(reinterpret_cast<unsigned int*>(p), CANARY_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -140,6 +148,51 @@ __device__ __forceinline__ float not_canary(float v) {
 __device__ __forceinline__ bool has_canary(f32x4 v) {
     const u32x4 u = __builtin_bit_cast(u32x4, v);
     return (u[0] == CANARY_BITS) | (u[1] == CANARY_BITS) | (u[2] == CANARY_BITS) | (u[3] == CANARY_BITS);
+}
+
+// Speculative protocol: make sure no loaded fragment still holds the canary (returns true if one did).  Runs before the
+// MFMAs; stale fragments are re-loaded per load instruction (a wave-uniform decision) until clean, bounded by SPIN_TICKS like
+// every other spin.  Also adapts the wave's first-attempt delay: +1 after a step that needed a re-load, -1 after 4 clean steps.
+template <int NCI, int NGI, typename LoadFrag>
+__device__ __forceinline__ bool validate_fragments(f32x4 (&bf)[NCI][NGI], LoadFrag& load_frag, bool first_chunk, int spec,
+                                                   int& spec_delay, int& spec_clean, SyncWs* sync, int& abort_flag,
+                                                   int& nretry) {
+    bool retried = false;
+    unsigned long long t_retry = 0;
+    for (;;) {
+        asm volatile("" ::: "memory");                            // (keeps re-loads from being hoisted or merged)
+        bool any = false;
+#pragma unroll
+        for (int gi = 0; gi < NGI; ++gi)
+#pragma unroll
+            for (int ci = 0; ci < NCI; ++ci)
+                if (__any(has_canary(bf[ci][gi]))) {
+                    any = true;
+                    load_frag(ci, gi);
+                }
+        if (!any) break;
+        ++nretry;
+        retried = true;
+        for (int i = 0; i < ((spec >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);
+        if (t_retry == 0) t_retry = __builtin_amdgcn_s_memrealtime();
+        if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {   // a payload never came: flag it, leave the launch
+            if ((threadIdx.x & 63) == 0) {
+                __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                abort_flag = 1;
+            }
+            break;
+        }
+    }
+    if (((spec >> 16) & 1) && first_chunk) {
+        if (retried) {
+            spec_delay = min(spec_delay + ((spec >> 18) & 3), 63);
+            spec_clean = 0;
+        } else if (++spec_clean == (1 << ((spec >> 20) & 7))) {
+            spec_clean = 0;
+            spec_delay = max(spec_delay - 1, 0);
+        }
+    }
+    return retried;
 }
 
 // wave 0 only (all 64 lanes call it): lane l < NSHARD polls shard l until it holds step * (slices in that shard)
@@ -652,10 +705,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     const int ncg = (nb + 3) >> 2;
     const int ng = (K + 63) >> 6;                       // 64-wide k groups
     const int slot_floats = ng * 64 * nb;               // a partial last quad keeps only its nb & 3 rows
-    // PROTO 0: drained hand-off; 1: signal first, drain later; 2: speculative loads, no per-step counters (see CANARY_BITS)
-    constexpr bool CAN = PROTO >= 1, SPEC = PROTO == 2;
-    constexpr int NSLOT = SPEC ? 4 : (CAN ? 3 : 2);
-    constexpr int CAHEAD = SPEC ? 2 : 1;                // the canary goes this many slots ahead of the payload
+    // PROTO 0: counted, drained hand-off; 2: speculative loads, no per-step counters (see CANARY_BITS)
+    constexpr bool SPEC = PROTO != 0, CAN = SPEC;
+    constexpr int NSLOT = SPEC ? 4 : 2;
+    constexpr int CAHEAD = 2;                           // the canary goes this many slots ahead of the payload
     // the wave that signals and polls: with the signal-first protocol the LAST wave, which has few or no gate threads (96 of
     // them in waves 0-1 at B = 10), so its arrival add does not queue behind its own hand-off stores
     constexpr int SIGW = CAN ? NWP - 1 : 0;
@@ -708,7 +761,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         if (abort_flag) return;
     }
     int scur = 0, sprev = NSLOT - 1;                    // slot written this step / read this step (= last step's)
-    int spec_delay = spec & 0xFF, spec_clean = 0;       // speculative protocol: see spec_timing()
+    int spec_delay = spec & 0xFF, spec_clean = 0, nretry = 0;   // speculative protocol: see spec_timing()
 
     for (int s = 0; s < T; ++s) {
         DS2_TICK(0);
@@ -752,71 +805,45 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 constexpr int NCI = decltype(nci_tag)::value;
                 f32x4 bf[NCI][NGI];
                 f32x4 acc[NRG][NCI];
-                unsigned long long t_retry = 0;
-              bool retried = false;
-              if (SPEC && c == 0)                                  // before the step's FIRST hand-off loads only
-                  for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
-              for (;;) {
-                asm volatile("" ::: "memory");                    // a retry must issue the loads again
+                if (SPEC && c == 0)                                // before the step's FIRST hand-off loads only
+                    for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
+                auto load_frag = [&](int ci, int gi) {
+                    const int g = wave + NWP * gi;                 // wave-uniform
+                    const int cg = c * CGW + ci;
+                    const int rows = min(4, nb - 4 * cg);          // batch rows this quad really has
+                    // lanes of rows past the batch (and k groups past K) read nothing: out-of-range offset -> 0
+                    // (k past K = 3H in the last group is never written by anyone and the ring is not cleared between
+                    // launches: it must not be read either)
+                    bf[ci][gi] = LOAD_HANDOFF(rs_x, (64 * g + 4 * kk < K && li < rows)
+                                                        ? (cg * ng * 256 + ((g * 16 + kk) * rows + li) * 4) * 4
+                                                        : OOB_OFFSET);
+                };
 #pragma unroll
                 for (int gi = 0; gi < NGI; ++gi)                   // k-group major: the MFMAs below consume in this order
 #pragma unroll
-                    for (int ci = 0; ci < NCI; ++ci) {
-                        const int g = wave + NWP * gi;             // wave-uniform
-                        const int cg = c * CGW + ci;
-                        const int rows = min(4, nb - 4 * cg);      // batch rows this quad really has
-                        // lanes of rows past the batch (and k groups past K) read nothing: out-of-range offset -> 0
-                        // (k past K = 3H in the last group is never written by anyone and the ring is not cleared between
-                        // launches: it must not be read either)
-                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (64 * g + 4 * kk < K && li < rows)
-                                                            ? (cg * ng * 256 + ((g * 16 + kk) * rows + li) * 4) * 4
-                                                            : OOB_OFFSET);
-                    }
+                    for (int ci = 0; ci < NCI; ++ci) load_frag(ci, gi);
                 // every load of the chunk goes out before the first MFMA: left alone the scheduler sinks loads in between
                 // the MFMAs and keeps only 2-5 in flight, which throttles a phase bounded by bytes in flight
                 __builtin_amdgcn_sched_barrier(0);
+                auto products = [&]() {
 #pragma unroll
-                for (int rg = 0; rg < NRG; ++rg)
+                    for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
-                    for (int ci = 0; ci < NCI; ++ci) acc[rg][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        for (int ci = 0; ci < NCI; ++ci) acc[rg][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int gi = 0; gi < NGI; ++gi)
+                    for (int gi = 0; gi < NGI; ++gi)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int ci = 0; ci < NCI; ++ci)
+                            for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
-                            for (int rg = 0; rg < NRG; ++rg)
-                                acc[rg][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[rg][gi][e], bf[ci][gi][e], acc[rg][ci], 0, 0, 0);
-                if (!CAN) break;
-                bool stale = false;                                // a fragment whose payload had not landed yet?
-#pragma unroll
-                for (int gi = 0; gi < NGI; ++gi)
-#pragma unroll
-                    for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][gi]);
-                if (!__any(stale)) break;
-                DS2_RETRY();
-                retried = true;
-                if (SPEC)
-                    for (int i = 0; i < ((spec >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);
-                if (t_retry == 0) t_retry = __builtin_amdgcn_s_memrealtime();
-                if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {   // a payload never came: flag it, leave the launch
-                    if (lane == 0) {
-                        __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        abort_flag = 1;
-                    }
-                    break;
-                }
-              }
-              if (SPEC && (spec >> 16) && c == 0) {   // adaptive first-attempt delay: +2 after a failed attempt, -1 after 8 clean steps
-                  if (retried) {
-                      spec_delay = min(spec_delay + 2, 63);
-                      spec_clean = 0;
-                  } else if (++spec_clean == 8) {
-                      spec_clean = 0;
-                      spec_delay = max(spec_delay - 1, 0);
-                  }
-              }
+                                for (int rg = 0; rg < NRG; ++rg)
+                                    acc[rg][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[rg][gi][e], bf[ci][gi][e], acc[rg][ci], 0, 0, 0);
+                };
+                // validate BEFORE the matrix work: a failed attempt then costs one more round trip for the stale fragments only.
+                // (Running the MFMAs optimistically first and repeating them after a re-load measured 15 % SLOWER per step.)
+                if (SPEC) validate_fragments<NCI, NGI>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync, abort_flag, nretry);
+                products();
                 // fold the 16 per-block partials: two DPP adds leave each 16-lane row's sum in its lanes 12..15
                 // (all the DPP adds first, as independent chains, then ONE predicated region with the stores: written value
                 // by value the compiler emits add_dpp / s_nop / mov_dpp / saveexec / add / ds_write / restore exec per value)
@@ -889,11 +916,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             sv_g = dn_pre * r;
         }
         if (CAN) {
-            // Signal-first hand-off stores: the arrival add queues behind them in the CU's memory pipe, so their NUMBER is
-            // on the signal's path.  Four neighbouring gate threads (units 4q .. 4q+3 of one batch row: adjacent lanes, 16
-            // contiguous bytes of the ring) hand their values to the first of them, which issues ONE 16-byte write-through
-            // store per gate and ONE 16-byte canary store into the next slot: 6 store instructions of a quarter of the
-            // lanes instead of 6 of all of them.  (UNITS and H are multiples of 4, so quads never straddle anything.)
+            // Hand-off stores of the speculative protocol: four neighbouring gate threads (units 4q .. 4q+3 of one batch row:
+            // adjacent lanes, 16 contiguous bytes of the ring) hand their values to the first of them, which issues ONE
+            // 16-byte write-through store per gate and ONE 16-byte canary store into the slot two ahead: 6 store instructions
+            // of a quarter of the lanes instead of 12 of all of them.  (UNITS and H are multiples of 4: quads never straddle.)
             float q[3][4];
 #define DS2_QUAD_BCAST(J)                                                                                              \
     q[0][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_r), (J) * 0x55, 0xF, 0xF, true));         \
@@ -926,6 +952,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         }
         DS2_TICK(5);
         if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (SPEC && (spec & (1 << 17))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // self-timed: see spec_timing()
         sprev = scur;
         scur = scur == NSLOT - 1 ? 0 : scur + 1;
         DS2_TICK(6);
@@ -945,6 +972,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         // polling wave (0) starts polling at once instead and drains after its poll has matched (its stores are old by then).
         if (CAN && !SPEC && wave != SIGW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    DS2_RETRY_FLUSH(nretry);
     if (tid == SIGW * 64) leave_kernel(sync);   // the thread whose arrival adds must have been performed first
 }
 
@@ -1006,9 +1034,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     const int ncg = (nb + 3) >> 2;
     const int ng = (H + 63) >> 6;
     const int slot_floats = ng * 64 * nb;
-    constexpr bool CAN = PROTO >= 1, SPEC = PROTO == 2;       // protocols: see the backward kernel and CANARY_BITS
-    constexpr int NSLOT = SPEC ? 4 : (CAN ? 3 : 2);
-    constexpr int CAHEAD = SPEC ? 2 : 1;
+    constexpr bool SPEC = PROTO != 0, CAN = SPEC;             // protocols: see the backward kernel and CANARY_BITS
+    constexpr int NSLOT = SPEC ? 4 : 2;
+    constexpr int CAHEAD = 2;
     float* my_ring = ring + (size_t)(dir * P + bpart) * NSLOT * ((size_t)ng * 64 * bper);
     if (tid == 0) abort_flag = 0;
 
@@ -1069,7 +1097,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         if (abort_flag) return;
     }
     int scur = 0, sprev = NSLOT - 1;                    // slot written this step / read this step (= last step's)
-    int spec_delay = spec & 0xFF, spec_clean = 0;       // speculative protocol: see spec_timing()
+    int spec_delay = spec & 0xFF, spec_clean = 0, nretry = 0;   // speculative protocol: see spec_timing()
 
     for (int s = 0; s < T; ++s) {
         const int t = dir == 0 ? s : T - 1 - s;
@@ -1108,26 +1136,24 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 constexpr int NCI = decltype(nci_tag)::value;
                 f32x4 bf[NCI][NGI];
                 f32x4 accA[NA][NCI][2], accB[NBS > 0 ? NBS : 1][NCI][2];
-                unsigned long long t_retry = 0;
-              bool retried = false;
-              if (SPEC && c == 0)                                  // before the step's FIRST hand-off loads only
-                  for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
-              for (;;) {
-                asm volatile("" ::: "memory");                    // a retry must issue the loads again
+                if (SPEC && c == 0)                                // before the step's FIRST hand-off loads only
+                    for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
+                auto load_frag = [&](int ci, int gi) {
+                    const int gq = wave + NWP * gi;                // wave-uniform k group
+                    const int cg = c * CGW + ci;
+                    const int rows = min(4, nb - 4 * cg);
+                    const int kk = 4 * g + q;
+                    // rows past the batch and k past H load nothing (out-of-range offset -> 0)
+                    bf[ci][gi] = LOAD_HANDOFF(rs_x, (64 * gq + 4 * kk < H && li < rows)
+                                                        ? (cg * ng * 256 + ((gq * 16 + kk) * rows + li) * 4) * 4
+                                                        : OOB_OFFSET);
+                };
 #pragma unroll
                 for (int gi = 0; gi < NGI; ++gi)
 #pragma unroll
-                    for (int ci = 0; ci < NCI; ++ci) {
-                        const int gq = wave + NWP * gi;            // wave-uniform k group
-                        const int cg = c * CGW + ci;
-                        const int rows = min(4, nb - 4 * cg);
-                        const int kk = 4 * g + q;
-                        // rows past the batch and k past H load nothing (out-of-range offset -> 0)
-                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (64 * gq + 4 * kk < H && li < rows)
-                                                            ? (cg * ng * 256 + ((gq * 16 + kk) * rows + li) * 4) * 4
-                                                            : OOB_OFFSET);
-                    }
+                    for (int ci = 0; ci < NCI; ++ci) load_frag(ci, gi);
                 __builtin_amdgcn_sched_barrier(0);                 // every load out before the first MFMA
+                auto products = [&]() {
                 // two chains per set and quad (e parity): a wave needs ~12 independent chains to issue every 10 cycles
 #pragma unroll
                 for (int ci = 0; ci < NCI; ++ci)
@@ -1159,35 +1185,11 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
 #undef DS2_FWD4_MFMA_A
 #undef DS2_FWD4_MFMA_B
                     }
-                if (!CAN) break;
-                bool stale = false;                                // a fragment whose payload had not landed yet?
-#pragma unroll
-                for (int gi = 0; gi < NGI; ++gi)
-#pragma unroll
-                    for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][gi]);
-                if (!__any(stale)) break;
-                DS2_RETRY();
-                retried = true;
-                if (SPEC)
-                    for (int i = 0; i < ((spec >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);
-                if (t_retry == 0) t_retry = __builtin_amdgcn_s_memrealtime();
-                if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {   // a payload never came: flag it, leave the launch
-                    if (lane == 0) {
-                        __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        abort_flag = 1;
-                    }
-                    break;
-                }
-              }
-              if (SPEC && (spec >> 16) && c == 0) {   // adaptive first-attempt delay: +2 after a failed attempt, -1 after 8 clean steps
-                  if (retried) {
-                      spec_delay = min(spec_delay + 2, 63);
-                      spec_clean = 0;
-                  } else if (++spec_clean == 8) {
-                      spec_clean = 0;
-                      spec_delay = max(spec_delay - 1, 0);
-                  }
-              }
+                };
+                // validate BEFORE the matrix work: a failed attempt then costs one more round trip for the stale fragments only.
+                // (Running the MFMAs optimistically first and repeating them after a re-load measured 15 % SLOWER per step.)
+                if (SPEC) validate_fragments<NCI, NGI>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync, abort_flag, nretry);
+                products();
                 // D register i = batch row i of the quad; lane (g, q, li): set A a -> gate row 4 (4 a + q) + li, k
                 // sub-index g; set B -> gate row 4 (4 NA + (q & 1)) + li, k sub-indices (g, q >> 1): one DPP add folds
                 // the two pairs
@@ -1263,6 +1265,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
             }
         }
         if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
+        if (SPEC && (spec & (1 << 17))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // self-timed: see spec_timing()
         sprev = scur;
         scur = scur == NSLOT - 1 ? 0 : scur + 1;
         __syncthreads();
@@ -1287,6 +1290,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         // wave drains after its poll instead
         if (CAN && !SPEC && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    DS2_RETRY_FLUSH(nretry);
     if (tid == 0) leave_kernel(sync);
 }
 
@@ -1302,10 +1306,17 @@ inline int spec_timing(int bwd) {
         const char* c = strchr(e, ',');
         if (c) backoff = atoi(c + 1);
     }
-    int adaptive = 1;
+    int adaptive = 1;                                  // bit 0: adapt the sleep count; bit 1: self-timed (wait for the own stores' acks)
     const char* a = getenv("DS2_GRU_SPEC_ADAPT");
     if (a) adaptive = atoi(a);
-    return (delay & 0xFF) | ((backoff & 0xFF) << 8) | (adaptive << 16);
+    int inc = 1, log2clean = 2;                        // adaptation: +inc after a step with a re-load, -1 after 2^log2clean clean ones
+    const char* pol = getenv("DS2_GRU_SPEC_POLICY");
+    if (pol) {
+        inc = atoi(pol);
+        const char* c = strchr(pol, ',');
+        if (c) log2clean = atoi(c + 1);
+    }
+    return (delay & 0xFF) | ((backoff & 0xFF) << 8) | ((adaptive & 3) << 16) | ((inc & 3) << 18) | ((log2clean & 7) << 20);
 }
 
 inline int pick_kbw(int need, const int* opts, int nopts) {
@@ -1488,11 +1499,11 @@ inline bool persistent_ok(int B, int H) {
            (ds2_cdiv(3 * H / 16, NWP) <= 19) && (ds2_cdiv(H / 16, NWP) <= 7);
 }
 
-// Hand-off protocol of the 4x4x1 forms: 0 drained, 1 signal first / drain later, 2 speculative loads (see CANARY_BITS).
+// Hand-off protocol of the 4x4x1 forms: 0 counted + drained, 2 speculative loads (see CANARY_BITS).
 // Default by the batch rows a workgroup handles: ONE batch quad (<= 4 rows: B <= 12 with three parts) -> speculative
 // (B = 10: 3.45 -> 3.1 us per step, B = 8: 2.9 -> 2.5, B = 4: 2.5 -> 1.9); with more rows the step is MFMA / store bound, the
 // canaries double the write-through stores and the drained protocol is faster (B = 32 backward: 6.4 vs 6.8 us, B = 64:
-// 11.3 vs 12.8).  DS2_GRU_PROTO = 0 / 1 / 2 forces one (A/B timing).
+// 11.3 vs 12.8).  DS2_GRU_PROTO = 0 / 2 forces one (A/B timing).
 inline int handoff_protocol(int rows_per_part) {
     const char* e = getenv("DS2_GRU_PROTO");
     if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
@@ -1570,9 +1581,8 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     if (use4) {
         const bool two = bper > rpp;
 #define DS2_FWD4_GO(P_, N_)                                                                                         \
-    (proto == 2 ? launch_fwd_persistent4<P_, N_, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)                \
-     : proto == 1 ? launch_fwd_persistent4<P_, N_, 1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)              \
-                  : launch_fwd_persistent4<P_, N_, 0>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
+    (proto != 0 ? launch_fwd_persistent4<P_, N_, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)                \
+                : launch_fwd_persistent4<P_, N_, 0>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
         const int proto = handoff_protocol(bper);
         if (parts == 1) ok = two ? DS2_FWD4_GO(1, 2) : DS2_FWD4_GO(1, 1);
         else if (parts == 2) ok = two ? DS2_FWD4_GO(2, 2) : DS2_FWD4_GO(2, 1);
@@ -1629,9 +1639,8 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     const bool ngi_ok = ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5;
     const int proto = handoff_protocol(ds2_cdiv(B, parts));
 #define DS2_BWD4_GO(R_)                                                                                             \
-    (proto == 2 ? launch_bwd_persistent4<R_, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)           \
-     : proto == 1 ? launch_bwd_persistent4<R_, 1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)         \
-                  : launch_bwd_persistent4<R_, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
+    (proto != 0 ? launch_bwd_persistent4<R_, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)           \
+                : launch_bwd_persistent4<R_, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
     if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);

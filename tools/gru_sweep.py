@@ -63,6 +63,6 @@ if __name__ == '__main__':
             fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
             buf = ctypes.c_uint(0)
             fn(ctypes.byref(buf), 1)
-            print('signal-first protocol: %d fragment re-loads in this process' % buf.value)
+            print('speculative protocol: %d re-load rounds (per wave and step) in this process' % buf.value)
         except AttributeError:
             pass
