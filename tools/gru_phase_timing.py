@@ -4,7 +4,9 @@ import ctypes, os, sys
 _ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(_ROOT, 'aes-lac-2018_amd')); sys.path.insert(0, _ROOT)
 import numpy as np, torch
-from ds2hip import lib, ops
+from ds2hip import lib
+lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), 'libds2hip_timing.so')
+from ds2hip import ops
 t, bsz, hid = 405, int(os.environ.get('BSZ', '10')), 800
 torch.manual_seed(0)
 w_hh = ((torch.rand(2, 3 * hid, hid) * 2 - 1) / hid ** 0.5).cuda()
@@ -18,8 +20,10 @@ fn = lib.load().ds2_debug_read_timing
 fn.argtypes = [ctypes.c_void_p]; fn.restype = ctypes.c_int
 assert fn(buf.ctypes.data) == 0
 tk = buf.reshape(32, 8).astype(np.float64)
-names = ['step top -> poll done', 'barrier after poll', 'loads + MFMA + fold', 'barrier before gates', 'LDS reduce + gate math + stores issued',
-         'store drain', 'barrier after drain', 'arrival add + saved stores -> next step top']
+names = ['step top (early loads issued) -> [counted protocol: poll done]', '[counted protocol: barrier after poll]',
+         'first-attempt delay + hand-off loads + validation + MFMA + fold', 'barrier before gates',
+         'LDS reduce + gate math + wait for old stores + hand-off stores issued', '[counted protocol: store drain]', 'barrier at the end of the step',
+         '[arrival add] + saved stores -> next step top']
 d = np.diff(np.concatenate([tk, np.roll(tk[:, :1], -1, axis=0)], axis=1), axis=1)[:-1]     # ticks per phase, 31 steps
 tot = d.sum(1)
 us_per_tick = float(os.environ.get('US_PER_STEP', '3.45')) / np.median(tot)     # s_memtime runs at the core clock (~2.36 GHz)
