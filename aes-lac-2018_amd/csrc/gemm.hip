@@ -123,29 +123,29 @@ __device__ __forceinline__ void store_slab(float* __restrict__ lds, int tid, con
     }
 }
 
+// XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b and b+8 share an L2.
+// Give every XCD a contiguous run of tiles (neighbours share an A panel) -- bijective for any tile count.
+__device__ __forceinline__ int xcd_tile(int wg, int nwg) {
+    const int xcd = wg & 7, idx = wg >> 3;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+}
+
+// one 128 x 128 tile over the k range of one split (the body of the single and of the grouped launch)
 template <bool A_KCONTIG, bool B_KCONTIG, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
-                                                          int lda, const float* __restrict__ B, int ldb,
-                                                          float* __restrict__ C, int ldc, float beta,
-                                                          int tiles_n, int k_per_split, int use_atomic,
-                                                          unsigned int a_bytes, unsigned int b_bytes) {
+__device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __restrict__ A, int lda,
+                                          const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc, float beta,
+                                          int tiles_n, int k_per_split, int use_atomic, unsigned int a_bytes,
+                                          unsigned int b_bytes, int tile, int split) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDT];  // [buf][A|B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b and b+8 share an L2.
-    // Give every XCD a contiguous run of tiles (neighbours share an A panel) -- bijective for any tile count.
-    int tile;
-    {
-        const int nwg = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int qd = nwg >> 3, rm = nwg & 7;
-        tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
-    }
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
-    const int kbeg = blockIdx.y * k_per_split;
+    const int kbeg = split * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
 
     f32x16 acc[2][2];
@@ -223,6 +223,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, c
                 }
             }
         }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A,
+                                                          int lda, const float* __restrict__ B, int ldb,
+                                                          float* __restrict__ C, int ldc, float beta,
+                                                          int tiles_n, int k_per_split, int use_atomic,
+                                                          unsigned int a_bytes, unsigned int b_bytes) {
+    gemm_tile<A_KCONTIG, B_KCONTIG, VEC>(M, N, K, A, lda, B, ldb, C, ldc, beta, tiles_n, k_per_split, use_atomic, a_bytes,
+                                         b_bytes, xcd_tile(blockIdx.x, gridDim.x), blockIdx.y);
+}
+
+// Up to four independent TN problems that share K and N in ONE launch (blockIdx.z = problem): the four weight-gradient
+// GEMMs dW_hh of a BiGRU layer (two directions x {r|z rows, n rows}) are 1600 x 800 and 800 x 800 outputs -- 91 and 49
+// tiles -- and ran at 74 / 58 TFLOP/s as separate launches; together they fill the chip like the 4800 x 800 dW_ih does.
+struct GemmGroup {
+    const float* A[4];
+    const float* B[4];
+    float* C[4];
+    int M[4], lda[4], ldb[4], ldc[4];
+    unsigned int a_bytes[4], b_bytes[4];
+};
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_tn_group_kernel(GemmGroup g, int N, int K, int tiles_n, int k_per_split) {
+    const int p = blockIdx.z;
+    const int tiles = ((g.M[p] + BM - 1) / BM) * tiles_n;
+    if ((int)blockIdx.x >= tiles) return;
+    gemm_tile<false, false, VEC>(g.M[p], N, K, g.A[p], g.lda[p], g.B[p], g.ldb[p], g.C[p], g.ldc[p], 0.f, tiles_n, k_per_split,
+                                 1, g.a_bytes[p], g.b_bytes[p], blockIdx.x, blockIdx.y);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -733,6 +762,66 @@ extern "C" int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
         ds2_set_error("ds2_gemm_f32: operand larger than 2 GB is not supported");
         return DS2_ERR_UNSUPPORTED;
     }
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}
+
+extern "C" int ds2_gemm_f32_tn_group(int count, const float* const* A_host, const int* lda_host, const int* M_host,
+                                     const float* const* B_host, const int* ldb_host, float* const* C_host,
+                                     const int* ldc_host, int N, int K, void* stream) {
+    DS2_CHECK_ARG(count >= 1 && count <= 4 && A_host && lda_host && M_host && B_host && ldb_host && C_host && ldc_host);
+    DS2_CHECK_ARG(N > 0 && K > 0);
+    GemmGroup g;
+    int max_tiles = 0, tot_tiles = 0;
+    const int tn = ds2_cdiv(N, BN);
+    bool vec = true;
+    for (int p = 0; p < 4; ++p) {
+        const int q = p < count ? p : 0;                        // unused slots repeat problem 0 (never launched)
+        DS2_CHECK_ARG(A_host[q] && B_host[q] && C_host[q] && M_host[q] > 0 && lda_host[q] >= M_host[q] && ldb_host[q] >= N &&
+                      ldc_host[q] >= N);
+        g.A[p] = A_host[q];
+        g.B[p] = B_host[q];
+        g.C[p] = C_host[q];
+        g.M[p] = M_host[q];
+        g.lda[p] = lda_host[q];
+        g.ldb[p] = ldb_host[q];
+        g.ldc[p] = ldc_host[q];
+        const unsigned long long ab = 4ull * ((unsigned long long)(K - 1) * lda_host[q] + M_host[q]);
+        const unsigned long long bb = 4ull * ((unsigned long long)(K - 1) * ldb_host[q] + N);
+        if (ab >= 0x7FFFFFF0ull || bb >= 0x7FFFFFF0ull) {
+            ds2_set_error("ds2_gemm_f32_tn_group: operand larger than 2 GB is not supported");
+            return DS2_ERR_UNSUPPORTED;
+        }
+        g.a_bytes[p] = (unsigned int)ab;
+        g.b_bytes[p] = (unsigned int)bb;
+        vec = vec && (lda_host[q] % 4 == 0) && (ldb_host[q] % 4 == 0) && (((uintptr_t)A_host[q] & 15) == 0) &&
+              (((uintptr_t)B_host[q] & 15) == 0);
+        if (p < count) {
+            const int t = ds2_cdiv(M_host[q], BM) * tn;
+            tot_tiles += t;
+            if (t > max_tiles) max_tiles = t;
+        }
+    }
+    // split K so that the launch has ~3 work items per resident slot (the rule of the single launch), >= 320 k per item
+    int split_k = 1;
+    if (tot_tiles < 512 && K >= 512) {
+        split_k = 3072 / tot_tiles;
+        const int max_split = K / 320 > 1 ? K / 320 : 1;
+        if (split_k > max_split) split_k = max_split;
+        if (split_k > 32) split_k = 32;
+        if (split_k < 1) split_k = 1;
+    }
+    int kper = ds2_cdiv(ds2_cdiv(K, split_k), BK) * BK;
+    if (kper < BK) kper = BK;
+    const int nsplit = ds2_cdiv(K, kper);
+    hipStream_t st = (hipStream_t)stream;
+    for (int p = 0; p < count; ++p)                              // partial products are accumulated with atomics
+        (void)hipMemset2DAsync(g.C[p], (size_t)g.ldc[p] * sizeof(float), 0, (size_t)N * sizeof(float), g.M[p], st);
+    dim3 grid(max_tiles, nsplit, count), block(256);
+    if (vec)
+        hipLaunchKernelGGL((gemm_f32_tn_group_kernel<true>), grid, block, 0, st, g, N, K, tn, kper);
+    else
+        hipLaunchKernelGGL((gemm_f32_tn_group_kernel<false>), grid, block, 0, st, g, N, K, tn, kper);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }

@@ -83,6 +83,14 @@ int ds2_gain_requantize(const float* x, const int64_t* offsets, const float* gai
  */
 int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
                  int ldb, float* C, int ldc, float beta, int split_k, void* stream);
+/* Up to four TN problems C_p[M_p, N] = A_p^T B_p that share N and K in ONE launch (A_p stored K x M_p with leading
+ * dimension lda_p, B_p stored K x N): the four weight-gradient GEMMs dW_hh of a BiGRU layer -- two directions x
+ * {r|z rows, n rows} of dGH^T h_prev, codes/model.py:51-52's backward -- which as separate launches are too small to fill
+ * the chip.  The pointer / size arrays are HOST arrays of `count` entries holding device pointers; K is split over
+ * workgroups and accumulated with float atomics into C (zero-filled by the call). */
+int ds2_gemm_f32_tn_group(int count, const float* const* A_host, const int* lda_host, const int* M_host,
+                          const float* const* B_host, const int* ldb_host, float* const* C_host, const int* ldc_host,
+                          int N, int K, void* stream);
 
 /* ------------------------------------------------------------------ conv stack
  * Replaces nn.Conv2d at codes/model.py:143-144 (cuDNN).  Layouts are NCHW with time innermost:

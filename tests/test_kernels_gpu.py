@@ -422,3 +422,21 @@ def test_release_library_ignores_the_debug_variable(ops, monkeypatch):
         res.append((g, ghn, hout))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_gemm_tn_group_matches_separate_launches(ops):
+    """The grouped TN launch (the four dW_hh problems of a BiGRU layer in one kernel) against fp64."""
+    rng = np.random.default_rng(11)
+    k, n = 1234, 200
+    ms = [400, 200, 400, 200]
+    a = [_t(rng.standard_normal((k, m + 8)).astype(np.float32)) for m in ms]          # leading dimension > M
+    b = [_t(rng.standard_normal((k, n)).astype(np.float32)) for _ in range(2)]
+    c = [torch.full((m, n), 7.0, device=DEV) for m in ms]                               # must be overwritten, not added to
+    problems = [(a[i].data_ptr(), a[i].shape[1], ms[i], b[i // 2].data_ptr(), n, c[i].data_ptr(), n) for i in range(4)]
+    ops.gemm_tn_group(problems, n, k)
+    for i in range(4):
+        ref = a[i].cpu().numpy()[:, :ms[i]].astype(np.float64).T @ b[i // 2].cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(c[i].cpu().numpy(), ref, rtol=0, atol=2e-6 * np.sqrt(k) * 4)
+    ops.gemm_tn_group(problems[:1], n, k)                                               # a group of one
+    ref = a[0].cpu().numpy()[:, :ms[0]].astype(np.float64).T @ b[0].cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(c[0].cpu().numpy(), ref, rtol=0, atol=2e-6 * np.sqrt(k) * 4)
