@@ -66,6 +66,11 @@ class Trainer(object):
         if self._fused:
             self._bind_momentum()
 
+    def reserve(self, nbytes):
+        """Grow the caching allocator's pool by one block of ``nbytes`` now, so that the first minibatch of every new
+        (longer) shape carves its activations out of it instead of paying a ``hipMalloc`` per tensor inside the step."""
+        torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+
     # ---------------------------------------------------------------- optimizer plumbing
     def _fused_ok(self):
         """The fused clip + Nesterov-SGD pass covers ``torch.optim.SGD`` with any number of parameter groups (the

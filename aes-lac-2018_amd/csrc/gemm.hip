@@ -131,28 +131,28 @@ __device__ __forceinline__ int xcd_tile(int wg, int nwg) {
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
 }
 
-// one 128 x 128 tile over the k range of one split (the body of the single and of the grouped launch)
-template <bool A_KCONTIG, bool B_KCONTIG, bool VEC>
-__device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __restrict__ A, int lda,
-                                          const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc, float beta,
-                                          int tiles_n, int k_per_split, int use_atomic, unsigned int a_bytes,
-                                          unsigned int b_bytes, int tile, int split) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDT];  // [buf][A|B]
-
+// one 128 x 128 tile over the k range of one split (the body of the single and of the grouped launch).
+// MODE 0: the four waves sit 2 x 2, 64 x 64 outputs = 4 MFMAs per k pair each.  MODE 1 / 2: an edge tile with at most 32 / 64
+// valid columns (N = 800 = 6 x 128 + 32: every seventh tile of dX, dW_ih and dW_hh): the waves stack in M (wave w = rows
+// 32 w .. 32 w + 31) and issue 1 / 2 MFMAs per k pair -- the tile then costs a quarter / half of the matrix-pipe time instead
+// of all of it for columns that do not exist (12 % of those GEMMs).  The choice is per workgroup, outside the slab loop.
+template <bool A_KCONTIG, bool B_KCONTIG, bool VEC, int MODE>
+__device__ __forceinline__ void gemm_tile_body(float (&lds)[2][2][BK * LDT], int M, int N, const float* __restrict__ A, int lda,
+                                               const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                               float beta, int use_atomic, unsigned int a_bytes, unsigned int b_bytes, int m0,
+                                               int n0, int kbeg, int kend) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = (tile / tiles_n) * BM;
-    const int n0 = (tile % tiles_n) * BN;
-    const int kbeg = split * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
+    constexpr int NI_ = MODE == 0 ? 2 : 1, NJ_ = MODE == 0 ? 2 : MODE;
+    const int arow = MODE == 0 ? wm * 64 : wave * 32, bcol = MODE == 0 ? wn * 64 : 0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI_][NJ_];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI_; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ_; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -178,24 +178,19 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __re
             load_slab<A_KCONTIG, VEC>(rsa, lda, m0, M, kbeg + (s + 1) * BK, kend, tid, ra);
             load_slab<B_KCONTIG, VEC>(rsb, ldb, n0, N, kbeg + (s + 1) * BK, kend, tid, rb);
         }
-        const float* as = lds[cur][0] + wm * 64 + lr;
-        const float* bs = lds[cur][1] + wn * 64 + lr;
+        const float* as = lds[cur][0] + arow + lr;
+        const float* bs = lds[cur][1] + bcol + lr;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a0, a1, b0, b1;
-            if (DS2_GEMM_ABL & 4) {
-                a0 = a1 = ra[0][0] + kk;
-                b0 = b1 = rb[0][0] + kk;
-            } else {
-                a0 = as[(kk + lh) * LDT];
-                a1 = as[(kk + lh) * LDT + 32];
-                b0 = bs[(kk + lh) * LDT];
-                b1 = bs[(kk + lh) * LDT + 32];
-            }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float a[NI_], b[NJ_];
+#pragma unroll
+            for (int i = 0; i < NI_; ++i) a[i] = (DS2_GEMM_ABL & 4) ? ra[0][0] + kk : as[(kk + lh) * LDT + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NJ_; ++j) b[j] = (DS2_GEMM_ABL & 4) ? rb[0][0] + kk : bs[(kk + lh) * LDT + 32 * j];
+#pragma unroll
+            for (int i = 0; i < NI_; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ_; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (s + 1 < nslab && !(DS2_GEMM_ABL & 1)) {
             store_slab<A_KCONTIG>(lds[cur ^ 1][0], tid, ra);
@@ -206,14 +201,14 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __re
 
     // C/D map of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI_; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + lr;
+        for (int j = 0; j < NJ_; ++j) {
+            const int n = n0 + bcol + j * 32 + lr;
             if (n >= N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + arow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m < M) {
                     float* c = C + (size_t)m * ldc + n;
                     if (use_atomic)
@@ -223,6 +218,28 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __re
                 }
             }
         }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, bool VEC>
+__device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __restrict__ A, int lda,
+                                          const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc, float beta,
+                                          int tiles_n, int k_per_split, int use_atomic, unsigned int a_bytes,
+                                          unsigned int b_bytes, int tile, int split) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][BK * LDT];  // [buf][A|B]
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int ncols = N - n0;                                            // wave-uniform (scalar) choice
+    if (ncols <= 32)
+        gemm_tile_body<A_KCONTIG, B_KCONTIG, VEC, 1>(lds, M, N, A, lda, B, ldb, C, ldc, beta, use_atomic, a_bytes, b_bytes, m0,
+                                                     n0, kbeg, kend);
+    else if (ncols <= 64)
+        gemm_tile_body<A_KCONTIG, B_KCONTIG, VEC, 2>(lds, M, N, A, lda, B, ldb, C, ldc, beta, use_atomic, a_bytes, b_bytes, m0,
+                                                     n0, kbeg, kend);
+    else
+        gemm_tile_body<A_KCONTIG, B_KCONTIG, VEC, 0>(lds, M, N, A, lda, B, ldb, C, ldc, beta, use_atomic, a_bytes, b_bytes, m0,
+                                                     n0, kbeg, kend);
 }
 
 template <bool A_KCONTIG, bool B_KCONTIG, bool VEC>
@@ -636,10 +653,12 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
                          // Measured on the weight-gradient shapes (tools/gemm_split_sweep.py): many small work items
                          // beat one round of big ones -- 4800x800x4050 TN: split 3 376 us, 8 318 us, 12 313 us -- so
                          // aim at ~3 items per slot while keeping >= 320 k (20 slabs) per item.
+        // Round 2, deep-K shapes with up to two rounds of tiles (dX at B = 32: 13000 x 800 x 4800 = 714 tiles): 1 split
+        // 1090 us, 4 959 us, 11 849 us -- ~8 items per slot, same floor per item.
         const int tiles = tm * tn;
         split_k = 1;
-        if (tiles < 512 && K >= 512) {
-            split_k = 3072 / tiles;
+        if ((tiles < 512 && K >= 512) || (tiles < 2048 && K >= 2048)) {
+            split_k = 8192 / tiles;
             const int max_split = K / 320 > 1 ? K / 320 : 1;
             if (split_k > max_split) split_k = max_split;
             if (split_k > 32) split_k = 32;

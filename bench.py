@@ -368,6 +368,8 @@ def main():
         inputs, pct = front(flat, offs)
         return trainer.update((inputs, labels, pct, lens))
 
+    if os.environ.get('DS2_BENCH_RESERVE_GB'):
+        trainer.reserve(int(float(os.environ['DS2_BENCH_RESERVE_GB']) * (1 << 30)))
     note('model built, inputs resident; timing')
     dt, per, loss = timed_steps(step, args.steps, args.warmup, use_dist)
     note('timed region done: %.2f ms/step' % (1e3 * dt / args.steps))
