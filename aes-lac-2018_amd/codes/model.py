@@ -163,6 +163,7 @@ class DeepSpeech(nn.Module):
         self._flat_g = None
         self._plist, self._offsets = [], []
         self.overlap_wgrad = os.environ.get('DS2_OVERLAP_WGRAD', '1') != '0'
+        self.defer_wgrad = os.environ.get('DS2_DEFER_WGRAD', '1') != '0'
         self._side = None
 
     # ------------------------------------------------------------------ flat parameter storage
@@ -364,6 +365,13 @@ class DeepSpeech(nn.Module):
         side = self._side_stream(gflat.device) if self.overlap_wgrad else None
         keepalive = []
         main.wait_event(sv['w_hh_t_ready'])
+        # The side stream's GEMMs of layer l are released only once the recurrence kernel of layer l - 1 has been LAUNCHED
+        # (an event recorded on the main stream right in front of it): a low-priority GEMM that is already running when the
+        # recurrence arrives keeps back-filling every CU that is only partly free, and the recurrence's 200 whole-CU
+        # workgroups are not all resident -- the ones that are spin -- until that GEMM has run out of workgroups
+        # (measured, rocprofv3 timeline at T = 495: 1.50 ms for the top layer's backward kernel, 1.88-1.94 ms for the four
+        # that started behind a 0.38 ms dW_hh GEMM).
+        pending = None
         for li in range(nl - 1, -1, -1):
             rec = sv['layers'][li]
             layer = self.rnns[li]
@@ -372,34 +380,47 @@ class DeepSpeech(nn.Module):
             w_ih = self._pair(r.weight_ih_l0, r.weight_ih_l0_reverse)
             w_hh_t = sv['w_hh_t'][li]                                               # transposed during forward
             gates, ghn, hout = rec['gates'], rec['ghn'], rec['hout']
+            if pending is not None:
+                gate = torch.cuda.Event()
+                gate.record(main)
             ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid)           # gates -> d(gi), ghn -> d(gh_n)
+            if pending is not None:
+                pending(gate)
+                pending = None
             dgi = gates.view(rows, 6 * hid)
             dxin = ops.gemm(dgi, w_ih, split_k=0)                                   # (rows, n_in): on the chain
             g_hh = (gv(r.weight_hh_l0), gv(r.weight_hh_l0_reverse))
             g_ih = self._pair_view(gflat, r.weight_ih_l0, r.weight_ih_l0_reverse)
-            if side is not None:
-                side.wait_stream(main)
-            with torch.cuda.stream(side if side is not None else main):
-                # dW_hh[d] = dGH[d]^T h_prev[d]; forward dir pairs step t with h[t-1], reverse with h[t+1]
-                if t > 1:
-                    k = (t - 1) * bsz
-                    step_g, step_n = bsz * 6 * hid * f4, bsz * 2 * hid * f4
-                    group = []                        # the four dW_hh problems of the layer in ONE launch
-                    for d in (0, 1):
-                        a_g = gates.data_ptr() + d * 3 * hid * f4 + (step_g if d == 0 else 0)
-                        a_n = ghn.data_ptr() + d * hid * f4 + (step_n if d == 0 else 0)
-                        hp = hout[d].data_ptr() + (0 if d == 0 else bsz * hid * f4)
-                        group.append((a_g, 6 * hid, 2 * hid, hp, hid, g_hh[d].data_ptr(), hid))
-                        group.append((a_n, 2 * hid, hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4, hid))
-                    if k <= 6144:                     # (B = 10: +0.6 % on the step; at B = 32, K ~ 16 k, one launch per problem
-                        ops.gemm_tn_group(group, hid, k)      # with its own finer split of K is 7 % faster)
+
+            def wgrad(gate, gates=gates, ghn=ghn, hout=hout, dgi=dgi, xin=rec['xin'], n_in=n_in, g_hh=g_hh, g_ih=g_ih,
+                      layer=layer, r=r):
+                if side is not None:
+                    side.wait_event(gate) if gate is not None else side.wait_stream(main)
+                with torch.cuda.stream(side if side is not None else main):
+                    # dW_hh[d] = dGH[d]^T h_prev[d]; forward dir pairs step t with h[t-1], reverse with h[t+1]
+                    if t > 1:
+                        k = (t - 1) * bsz
+                        step_g, step_n = bsz * 6 * hid * f4, bsz * 2 * hid * f4
+                        group = []                        # the four dW_hh problems of the layer in ONE launch
+                        for d in (0, 1):
+                            a_g = gates.data_ptr() + d * 3 * hid * f4 + (step_g if d == 0 else 0)
+                            a_n = ghn.data_ptr() + d * hid * f4 + (step_n if d == 0 else 0)
+                            hp = hout[d].data_ptr() + (0 if d == 0 else bsz * hid * f4)
+                            group.append((a_g, 6 * hid, 2 * hid, hp, hid, g_hh[d].data_ptr(), hid))
+                            group.append((a_n, 2 * hid, hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4, hid))
+                        if k <= 6144:                     # (B = 10: +0.6 % on the step; at B = 32, K ~ 16 k, one launch per
+                            ops.gemm_tn_group(group, hid, k)      # problem with its own finer split of K is 7 % faster)
+                        else:
+                            for a_p, lda, m_p, b_p, ldb, c_p, ldc in group:
+                                ops.gemm_raw(1, 0, m_p, hid, k, a_p, lda, b_p, ldb, c_p, ldc, split_k=0)
                     else:
-                        for a_p, lda, m_p, b_p, ldb, c_p, ldc in group:
-                            ops.gemm_raw(1, 0, m_p, hid, k, a_p, lda, b_p, ldb, c_p, ldc, split_k=0)
-                else:
-                    g_hh[0].zero_()
-                    g_hh[1].zero_()
-                ops.gemm(dgi, rec['xin'].view(rows, n_in), trans_a=True, out=g_ih, split_k=0)  # dW_ih (both dirs)
+                        g_hh[0].zero_()
+                        g_hh[1].zero_()
+                    ops.gemm(dgi, xin.view(rows, n_in), trans_a=True, out=g_ih, split_k=0)  # dW_ih (both dirs)
+                if grad_ready is not None:
+                    first = layer.batch_norm.module.weight if layer.batch_norm is not None else r.weight_ih_l0
+                    grad_ready(*self._span(first, r.weight_hh_l0_reverse), also_wait=side)
+
             if layer.batch_norm is not None:
                 bn = layer.batch_norm.module
                 below = sv['layers'][li - 1]['hout']
@@ -407,12 +428,15 @@ class DeepSpeech(nn.Module):
                                   gv(bn.bias))
             else:
                 dy = dxin
-            if grad_ready is not None:
-                first = layer.batch_norm.module.weight if layer.batch_norm is not None else r.weight_ih_l0
-                grad_ready(*self._span(first, r.weight_hh_l0_reverse), also_wait=side)
+            if side is not None and self.defer_wgrad:
+                pending = wgrad                    # released behind the next layer's recurrence launch
+            else:
+                wgrad(None)
             if side is not None:
                 keepalive.append(dict(rec))        # the side stream still reads these; freed after the join below
             rec.clear()
+        if pending is not None:                    # the bottom layer's: beside the conv block's backward
+            pending(None)
         # The side stream may still be working through weight-gradient GEMMs (it only gets the CUs the recurrence
         # kernels leave free): the conv block's backward below runs beside that backlog, and the ONE join with the
         # side stream is at the end of this function.  `keepalive` keeps the tensors it reads allocated until then.

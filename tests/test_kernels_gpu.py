@@ -25,15 +25,16 @@ def _t(a):
 @pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize('m,n,k', [(128, 128, 16), (300, 200, 100), (37, 29, 800), (1000, 4800, 672),
                                    (29, 800, 555), (5, 7, 3), (257, 129, 33),
-                                   (4240, 4800, 800), (3001, 2999, 301), (2100, 4000, 17), (8200, 4100, 40)])
+                                   (4240, 4800, 800), (3001, 2999, 301), (2100, 4000, 17), (8200, 4100, 40),
+                                   (1330, 800, 4800), (260, 192, 2100)])     # edge tiles of 32 / 64 columns + split-K
 def test_gemm_matches_fp64(ops, ta, tb, m, n, k):
     rng = np.random.default_rng(m * 7 + n * 3 + k + ta * 2 + tb)
     a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
     b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
     ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
     out = ops.gemm(_t(a), _t(b), trans_a=bool(ta), trans_b=bool(tb)).cpu().numpy()
-    scale = np.sqrt(k)
-    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6 * scale * 4)
+    # fp32 accumulation noise: rounding of partial sums whose magnitude grows like sqrt(k), over k terms (outputs ~ sqrt(k))
+    np.testing.assert_allclose(out, ref, rtol=0, atol=max(8e-6 * np.sqrt(k), 4e-7 * k))
 
 
 def test_gemm_beta_and_splitk(ops):
