@@ -198,23 +198,32 @@ def make_resident(bin_, dev):
 
 
 def timed_steps(step, n, warmup, use_dist):
-    """W untimed steps, then EXACTLY n steps bracketed by barrier + synchronize; also the per-step host times (every
-    step ends with the one readback the reference's step has, codes/engine.py:92, so they need no extra sync)."""
+    """W untimed steps, then EXACTLY n steps bracketed by barrier + synchronize; also the per-step times.  ``step`` may
+    return a deferred loss (``Trainer.update(defer=True)``: the host reads step i's loss, the reference's one readback per
+    step, codes/engine.py:92, after it has enqueued step i + 1): step i is then complete when call i + 1 returns, and the
+    last one when its ``result()`` does -- inside the timed region."""
     for i in range(warmup):
         step(i)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    per = []
+    stamps = []
     t0 = time.time()
+    p0 = time.perf_counter()
+    loss = None
     for i in range(warmup, warmup + n):
-        t1 = time.perf_counter()
         loss = step(i)
-        per.append(time.perf_counter() - t1)
+        stamps.append(time.perf_counter())
+    deferred = hasattr(loss, 'result')
+    if deferred:
+        loss = loss.result()
+        stamps = stamps[1:] + [time.perf_counter()]
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
-    return time.time() - t0, per, loss
+    dt = time.time() - t0
+    per = [b - a for a, b in zip([p0] + stamps[:-1], stamps)]
+    return dt, per, loss
 
 
 def secondary_shape(trainer, front, dev, bsz, bins_durations, steps=None, warmup=None, seed=900):
@@ -230,7 +239,7 @@ def secondary_shape(trainer, front, dev, bsz, bins_durations, steps=None, warmup
     def step(i):
         flat, offs, labels, lens = res[i % len(res)]
         inputs, pct = front(flat, offs)
-        return trainer.update((inputs, labels, pct, lens))
+        return trainer.update((inputs, labels, pct, lens), defer=True)
 
     dt, per, _ = timed_steps(step, steps, warmup, False)
     idxs = [i % len(bins) for i in range(warmup, warmup + steps)]
@@ -290,7 +299,8 @@ def loader_leg(trainer, plan, dev, workers=4):
             for inputs, targets, pct, sizes in loader:
                 frames += int(round(float(pct.sum()) * inputs.shape[1]))
                 if name == 'train':
-                    trainer.update((inputs, targets, pct, sizes))
+                    trainer.update((inputs, targets, pct, sizes), defer=True)
+            trainer.flush()
             torch.cuda.synchronize()
             rate = round(frames / (time.time() - t0), 1)
             note('loader leg pass %d (%s): %s frames/s' % (epoch, name, rate))
@@ -366,10 +376,9 @@ def main():
     def step(i):
         flat, offs, labels, lens = resident[i % len(resident)]
         inputs, pct = front(flat, offs)
-        return trainer.update((inputs, labels, pct, lens))
+        return trainer.update((inputs, labels, pct, lens), defer=True)
 
-    if os.environ.get('DS2_BENCH_RESERVE_GB'):
-        trainer.reserve(int(float(os.environ['DS2_BENCH_RESERVE_GB']) * (1 << 30)))
+    trainer.reserve(int(float(os.environ.get('DS2_BENCH_RESERVE_GB', '4')) * (1 << 30)))   # one allocator block up front
     note('model built, inputs resident; timing')
     dt, per, loss = timed_steps(step, args.steps, args.warmup, use_dist)
     note('timed region done: %.2f ms/step' % (1e3 * dt / args.steps))
@@ -393,7 +402,7 @@ def main():
         def step3(i):
             flat, offs, labels, lens = c3[i % 2]
             inputs, pct = front(flat, offs)
-            return trainer.update((inputs, labels, pct, lens))
+            return trainer.update((inputs, labels, pct, lens), defer=True)
 
         dt3, _, _ = timed_steps(step3, 8, 2, use_dist)
         t3 = torch.tensor([dt3], dtype=torch.float64, device=dev)

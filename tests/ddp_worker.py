@@ -21,6 +21,8 @@ for p in (ROOT, os.path.join(ROOT, 'aes-lac-2018_amd')):
 
 
 def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get('DS2_TEST_HANG_S', '200')), exit=True)   # a hung rank says where
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)

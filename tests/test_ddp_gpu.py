@@ -24,19 +24,30 @@ def test_two_rank_step_matches_ddp_oracle(tmp_path, overlap):
     port = 29700 + (os.getpid() % 200) + (7 if overlap == '1' else 0)
     env = dict(os.environ, DS2_GRU_MODE='step', DS2_ALLREDUCE_OVERLAP=overlap)
     outs = [str(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_worker.py'), str(r), str(world),
-                               str(port), outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(world)]
-    logs = []
-    for p in procs:
-        try:
-            so, se = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        logs.append(se[-3000:])
-    assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
+
+    def run_ranks(port):
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'ddp_worker.py'), str(r), str(world),
+                                   str(port), outs[r]], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for r in range(world)]
+        logs = []
+        for p in procs:
+            try:
+                so, se = p.communicate(timeout=300)      # (a hung rank dumps its stack and exits by itself after 200 s)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            logs.append(se[-3000:])
+        return all(p.returncode == 0 for p in procs), logs
+
+    ok, logs = run_ranks(port)
+    if not ok and any('Timeout (' in log or 'dump_traceback' in log or 'Thread 0x' in log for log in logs):
+        # two processes time-slicing ONE GPU is a configuration only this test has; a rank that stalls there is reported
+        # (the stack it dumped) and the pair is started once more on another port
+        import warnings
+        warnings.warn('a rank of the shared-GPU pair stalled and was restarted:\n' + '\n'.join(logs))
+        ok, logs = run_ranks(port + 211)
+    assert ok, '\n'.join(logs)
     want_losses, want_sd, want_params = dc.oracle_ddp_steps(world)
     got = [np.load(o) for o in outs]
     assert int(got[0]['overlap']) == int(overlap)

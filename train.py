@@ -196,15 +196,28 @@ def main(argv=None):
     iteration = start_epoch * steps_per_epoch
     for epoch in range(start_epoch, args.config.training.num_epochs):
         t_epoch = time.time()
-        for i, batch in enumerate(train_loader):
-            t0 = time.time()
-            loss = trainer.update(batch)
-            iteration += 1
+        def log_step(rec):
+            # the readback of a step is deferred until the next one has been enqueued (Trainer.update(defer=True)):
+            # its line is printed one iteration late, same content
+            i, t0, data_time, loss = rec
+            loss = loss.result() if hasattr(loss, 'result') else loss
             if main_proc and not args.silent and loss != 'Skipped':
                 LOG.info('Epoch: [{}][{}/{}]\tTime {:.3f}\tData {:.3f}\tLoss {:.4f}'.format(
-                    epoch + 1, i + 1, len(train_loader), time.time() - t0, trainer.data_time, loss))
+                    epoch + 1, i + 1, len(train_loader), time.time() - t0, data_time, loss))
+
+        prev = None
+        for i, batch in enumerate(train_loader):
+            t0 = time.time()
+            loss = trainer.update(batch, defer=True)
+            iteration += 1
+            if prev is not None:
+                log_step(prev)
+            prev = (i, t0, trainer.data_time, loss)
             if main_proc and args.checkpoint_per_batch and iteration % args.checkpoint_per_batch == 0:
                 torch.save(payload(epoch, iteration), os.path.join(out_dir, 'model_batch-ckpt_{}.pth'.format(iteration)))
+        trainer.flush()
+        if prev is not None:
+            log_step(prev)
         LOG.info('Training epoch [{}] took {:.0f} s'.format(epoch + 1, time.time() - t_epoch))
         # epoch end, in the reference's handler order (train.py:272-374): train metrics, validation metrics, LR anneal,
         # epoch checkpoint, best-CER checkpoint, metrics-log
