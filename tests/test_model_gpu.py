@@ -200,6 +200,49 @@ def test_full_size_step_properties():
     np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+def test_deferred_readback_gives_the_same_steps():
+    """``Trainer.update(defer=True)`` (the host reads step i's loss after enqueuing step i + 1) against the synchronous
+    form: same losses, gradient norm and parameters; ``run()`` reports every step exactly once."""
+    from codes.engine import PendingLoss, Trainer
+    from codes.model import DeepSpeech
+    kw = dict(rnn_hidden_size=96, num_rnn_layers=2, num_classes=29)
+    rng = np.random.default_rng(5)
+    batches = []
+    for t_in in (181, 240, 121, 240):
+        x = torch.from_numpy(rng.standard_normal((3, t_in, 161)).astype(np.float32))
+        lens = [int(v) for v in rng.integers(3, 12, size=3)]
+        labels = torch.from_numpy(rng.integers(1, 29, size=sum(lens)).astype(np.int32))
+        batches.append((x, labels, torch.ones(3), torch.tensor(lens, dtype=torch.int32)))
+    runs = []
+    for mode in ('sync', 'defer', 'run'):
+        torch.manual_seed(3)
+        model = DeepSpeech(**kw).to('cuda')
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True)
+        tr = Trainer(model, opt, device='cuda', max_norm=50)
+        if mode == 'sync':
+            losses = [tr.update(b) for b in batches]
+        elif mode == 'defer':
+            handles = [tr.update(b, defer=True) for b in batches]
+            assert all(isinstance(h, PendingLoss) for h in handles)
+            assert all(h._value is not None for h in handles[:-1])       # resolved when the next step was enqueued
+            assert tr.flush() == handles[-1].result()
+            losses = [h.result() for h in handles]
+        else:
+            seen = []
+            tr.run(batches, num_epochs=1, on_iteration=lambda t, e, i, loss: seen.append((i, loss)))
+            assert [i for i, _ in seen] == list(range(len(batches)))
+            losses = [v for _, v in seen]
+        runs.append((losses, tr.last_grad_norm, [p.detach().clone() for p in model.parameters()], tr.iteration))
+    # (not bit-for-bit: the split-K weight-gradient GEMMs add their partial products with float atomics, in an order that
+    # changes from run to run -- two synchronous runs differ in the last bits too)
+    for losses, norm, params, it in runs[1:]:
+        np.testing.assert_allclose(losses, runs[0][0], rtol=1e-5)
+        np.testing.assert_allclose(norm, runs[0][1], rtol=1e-5)
+        assert it == len(batches)
+        for a, b in zip(params, runs[0][2]):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6)
+
+
 def test_beam_decoder_agrees_with_greedy_on_confident_outputs():
     """A width-1..16 prefix beam search returns the greedy transcript when every frame is confident."""
     from codes.decoder import BeamCTCDecoder, GreedyDecoder
