@@ -646,6 +646,156 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
     if (tid == 0) leave_kernel(sync);
 }
 
+// Backward recurrence, 16x16x4 form with TWO batch parts (blockIdx.z), the twin of gru_fwd_persistent_p2_kernel: a
+// workgroup owns 16 units -- 16 rows of w_hh_t, a whole MFMA tile (the 8-unit form above pads half of every tile) -- and
+// half the batch, so per step it pulls HALF of d(gh) (150 KB at B = 32 instead of 300) and issues NBT x 150 / 8 x 4 MFMAs
+// per wave.  For B >= 17: the 4x4x1 forms' cost grows with every batch quad (B = 32: 7.0 us per step, B = 64: 12.3), this
+// form's with every tile of 16 rows per part.  The hand-off loads of k chunk c + 1 are in flight under the MFMAs of chunk c.
+template <int NBT, int KBW>
+__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                         const float* __restrict__ hout,
+                                                                         const float* __restrict__ d_out,
+                                                                         const float* __restrict__ w_hh_t,
+                                                                         SyncWs* __restrict__ sync, float* __restrict__ ring,
+                                                                         int T, int B, int H, int dbg) {
+    __shared__ float red[NWP][NBT][16][17];
+    __shared__ int abort_flag;
+    constexpr int UNITS = 16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
+    const int j0 = blockIdx.x * UNITS;
+    const int m = lane & 15, q = lane >> 4;
+    const int K = 3 * H, nkb = K >> 4;
+    const int bper = (B + 1) / 2, b0 = part * bper, nb = min(bper, B - b0);
+    if (nb <= 0) {
+        if (tid == 0) leave_kernel(sync);
+        return;
+    }
+    const int slot_floats = NBT * nkb * 256;
+    float* my_ring = ring + (size_t)(dir * 2 + part) * 2 * slot_floats;
+    if (tid == 0) abort_flag = 0;
+
+    f32x4 wreg[KBW];                                   // row m: column (j0 + m) of W_hh = row of w_hh_t
+    {
+        const bool unit_ok = (j0 + m) < H;
+        const float* row = w_hh_t + ((size_t)dir * H + (unit_ok ? j0 + m : 0)) * K;
+#pragma unroll
+        for (int i = 0; i < KBW; ++i) {
+            const int kb = wave + NWP * i;
+            wreg[i] = (unit_ok && kb < nkb) ? *reinterpret_cast<const f32x4*>(row + kb * 16 + q * 4)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // gate role: unit jj, local batch row 16 gbt + nn  (512 threads = 16 units x 32 rows)
+    const int jj = tid & 15, nn = (tid >> 4) & 15, gbt = tid >> 8;
+    const int lb = gbt * 16 + nn, gb = b0 + lb, gj = j0 + jj;
+    const bool gate_ok = (gbt < NBT) && (lb < nb) && (gj < H);
+    float dhz = 0.f;                                    // dh * z carried to the next (earlier) step
+    unsigned int* shards = &sync->arrive[dir][part][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? T - 1 - s : s;
+        const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
+        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
+        size_t row = 0, gbase = 0;
+        if (gate_ok) {                                  // saved activations of step t: plain loads, issued before the wait
+            row = ((size_t)t * B + gb) * 2 + dir;
+            gbase = row * 3 * H + gj;
+            dh = d_out[((size_t)t * B + gb) * H + gj];
+            r = G[gbase];
+            z = G[gbase + H];
+            n = G[gbase + 2 * H];
+            gn = ghn[row * H + gj];
+            if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
+        }
+        if (s > 0) {
+            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
+                abort_flag = 1;
+            __syncthreads();
+            if (abort_flag) return;
+            // d(gh) of the previous step of this (direction, part): [batch tile][k block][k quad 4][16 batch rows][4 k]
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
+            constexpr int CH = KBW > 10 ? 7 : KBW;     // stages = (batch tile, k chunk)
+            constexpr int NCH = (KBW + CH - 1) / CH;
+            constexpr int NST = NBT * NCH;
+            f32x4 bf[2][CH];
+            auto fetch = [&](int st, f32x4 (&dst)[CH]) {
+                const int bt = st / NCH, i0 = (st % NCH) * CH;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int i = i0 + c;
+                    const int kb = wave + NWP * i;                 // wave-uniform
+                    if (i < KBW)                                   // compile-time
+                        dst[c] = LOAD_HANDOFF(rs_x, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
+                    else
+                        dst[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            };
+            if (!DS2_DBG(dbg, 2)) {
+                fetch(0, bf[0]);
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    if (st + 1 < NST) fetch(st + 1, bf[(st + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);   // loads out before the MFMAs
+                    const int bt = st / NCH, i0 = (st % NCH) * CH;
+#pragma unroll
+                    for (int c = 0; c < CH; ++c)
+                        if (i0 + c < KBW) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i0 + c][e], bf[st & 1][c][e], acc, 0, 0, 0);
+                        }
+                    if ((st % NCH) == NCH - 1) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) red[wave][bt][4 * q + rr][m] = acc[rr];
+                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (gate_ok) {
+            if (s > 0) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWP; ++w) a += red[w][gbt][jj][nn];
+                dh += a + dhz;
+            }
+            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+            const float dz_pre = dh * (hpv - n) * z * (1.f - z);
+            const float dr_pre = dn_pre * gn * r * (1.f - r);
+            dhz = dh * z;
+            {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
+                float* slot = my_ring + (size_t)(s & 1) * slot_floats + (size_t)gbt * nkb * 256 + nn * 4;
+                const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
+                store_sc1(&slot[(size_t)(k0 >> 4) * 256 + ((k0 & 15) >> 2) * 64 + (k0 & 3)], dr_pre);
+                store_sc1(&slot[(size_t)(k1 >> 4) * 256 + ((k1 & 15) >> 2) * 64 + (k1 & 3)], dz_pre);
+                store_sc1(&slot[(size_t)(k2 >> 4) * 256 + ((k2 & 15) >> 2) * 64 + (k2 & 3)], dn_pre * r);
+            }
+            sv_r = dr_pre;
+            sv_z = dz_pre;
+            sv_n = dn_pre;
+            sv_g = dn_pre * r;
+        }
+        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
+            G[gbase] = sv_r;
+            G[gbase + H] = sv_z;
+            G[gbase + 2 * H] = sv_n;
+            ghn[row * H + gj] = sv_g;
+        }
+    }
+    if (tid == 0) leave_kernel(sync);
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // Backward recurrence on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per instruction).
 //
@@ -1392,6 +1542,29 @@ bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float*
     return false;
 }
 
+template <int NBT>
+bool launch_bwd_persistent_p2(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
+                              SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
+    const int opts[] = {1, 2, 4, 8, 19};
+    const int kbw = pick_kbw(ds2_cdiv(3 * H / 16, NWP), opts, 5);
+    dim3 grid(ds2_cdiv(H, 16), 2, 2), block(NWP * 64);
+#define DS2_BWDP2_CASE(K)                                                                                          \
+    case K:                                                                                                        \
+        if (!grid_is_coresident(&gru_bwd_persistent_p2_kernel<NBT, K>, grid, 0)) return false;                     \
+        hipLaunchKernelGGL((gru_bwd_persistent_p2_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, \
+                           sync, ring, T, B, H, dbg);                                                              \
+        return true;
+    switch (kbw) {
+        DS2_BWDP2_CASE(1)
+        DS2_BWDP2_CASE(2)
+        DS2_BWDP2_CASE(4)
+        DS2_BWDP2_CASE(8)
+        DS2_BWDP2_CASE(19)
+    }
+#undef DS2_BWDP2_CASE
+    return false;
+}
+
 template <int P, int NBT, int PROTO>
 bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
                             int H, int dbg, hipStream_t st) {
@@ -1531,7 +1704,8 @@ inline int dbg_flags() {
 // counter form -- 1600 waves polling payload lines swamp the fabric ("polling-cost" row of the price list).
 // exchange ring: [dir 2][slot 2][batch tiles][k blocks of 16][16][16] floats, sized for the backward pass (K = 3H)
 inline size_t ring_floats(int B, int H) {
-    const size_t a = (size_t)ds2_cdiv(B, 16) * (size_t)(3 * H / 16) * 256;          // 16x16x4 forms
+    const int tiles16 = ds2_cdiv(B, 16) > 2 * ds2_cdiv(ds2_cdiv(B, 2), 16) ? ds2_cdiv(B, 16) : 2 * ds2_cdiv(ds2_cdiv(B, 2), 16);
+    const size_t a = (size_t)tiles16 * (size_t)(3 * H / 16) * 256;                    // 16x16x4 forms (whole batch / two parts)
     const size_t b2 = (size_t)2 * ds2_cdiv(B, 2), b3 = (size_t)3 * ds2_cdiv(B, 3);
     const size_t b = (b2 > b3 ? b2 : b3) * (size_t)ds2_cdiv(3 * H, 64) * 64;          // 4x4x1 forms (1-3 batch parts)
     return (size_t)2 * (2 * a > 4 * b ? 2 * a : 4 * b);                              // two slots / up to four (canary protocols)
@@ -1616,8 +1790,13 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
     float* ring = (float*)((char*)sync_ws + header_bytes());
     const int dbg = dbg_flags();
     bool ok;
-    const char* form = getenv("DS2_GRU_BWD");   // "16" selects the 16x16x4 MFMA form (A/B timing); default: 4x4x1
-    const bool use4 = form ? form[0] == '4' : true;
+    // Form: the 4x4x1 forms up to B = 16; from B = 17 the two-part 16x16x4 form (us per step at H = 800, B = 32 / 64: 4x4x1
+    // 7.0 / 12.3, see gru_bwd_persistent_p2_kernel).  DS2_GRU_BWD = "4" / "16" forces a family, DS2_GRU_BWD_P2 = 0 / 1 the
+    // two-part 16x16x4 form off / on (A/B timing).
+    const char* form = getenv("DS2_GRU_BWD");
+    const char* p2e = getenv("DS2_GRU_BWD_P2");
+    const bool p2 = (p2e ? p2e[0] == '1' : (B >= 17 && !(form && form[0] == '4'))) && B >= 2 && H % 16 == 0;
+    const bool use4 = !p2 && (form ? form[0] == '4' : true);
     // Batch parts (1, 2 or 3: 8, 16 or 24 units per workgroup) by the fitted cost model; measured, H = 800, us per step,
     // whole batch / two halves: B=8 3.32 / 2.98, B=10 3.90 / 4.04, B=16 4.77 / 4.09, B=32 7.48 / 6.51, B=64 12.84 / 11.38.
     // DS2_GRU_BWD_SPLIT = 1 / 2 / 3 forces a form (A/B timing).
@@ -1641,7 +1820,10 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
 #define DS2_BWD4_GO(R_)                                                                                             \
     (proto != 0 ? launch_bwd_persistent4<R_, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)           \
                 : launch_bwd_persistent4<R_, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
-    if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
+    if (p2)
+        ok = (B + 1) / 2 <= 16 ? launch_bwd_persistent_p2<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
+                               : launch_bwd_persistent_p2<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);
     else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
