@@ -480,14 +480,27 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* 
             const float n = fast_tanh(gi_n + r * gh_n);
             const float h = (1.f - z) * n + z * hp;
             hp = h;
-            // exchange ring of this (direction, part): [batch tile][k block][k quad 4][16 batch rows][4 k]
-            store_sc1(&my_ring[(size_t)(s & 1) * slot_floats + ((size_t)gbt * nkb + (gj >> 4)) * 256 + ((gj & 15) >> 2) * 64 +
-                               nn * 4 + (gj & 3)], h);
             sv_h = h;
             sv_r = r;
             sv_z = z;
             sv_n = n;
             sv_g = gh_n;
+        }
+        {
+            // exchange ring of this (direction, part): [batch tile][k block][k quad 4][16 batch rows][4 k].  Four neighbouring
+            // gate threads (units 4u .. 4u+3 of one batch row: adjacent lanes, 16 contiguous bytes of the ring) hand their
+            // values to the first of them, which issues ONE 16-byte write-through store: a quarter of the fabric writes
+            // (a 4-byte sc1 store costs about six times a 16-byte one per byte).  H % 16 == 0: a quad never straddles H.
+            f32x4 hq;
+            hq[0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_h), 0x00, 0xF, 0xF, true));
+            hq[1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_h), 0x55, 0xF, 0xF, true));
+            hq[2] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_h), 0xAA, 0xF, 0xF, true));
+            hq[3] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_h), 0xFF, 0xF, 0xF, true));
+            if (gate_ok && (jj & 3) == 0) {
+                const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, 2 * slot_floats * 4, 0x00020000);
+                store_sc1_b128(rs_w, ((s & 1) * slot_floats + (gbt * nkb + (gj >> 4)) * 256 + ((gj & 15) >> 2) * 64 + nn * 4) * 4,
+                               __builtin_bit_cast(u32x4, hq));
+            }
         }
         if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -771,17 +784,33 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2_kernel(float* 
             const float dz_pre = dh * (hpv - n) * z * (1.f - z);
             const float dr_pre = dn_pre * gn * r * (1.f - r);
             dhz = dh * z;
-            {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
-                float* slot = my_ring + (size_t)(s & 1) * slot_floats + (size_t)gbt * nkb * 256 + nn * 4;
-                const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
-                store_sc1(&slot[(size_t)(k0 >> 4) * 256 + ((k0 & 15) >> 2) * 64 + (k0 & 3)], dr_pre);
-                store_sc1(&slot[(size_t)(k1 >> 4) * 256 + ((k1 & 15) >> 2) * 64 + (k1 & 3)], dz_pre);
-                store_sc1(&slot[(size_t)(k2 >> 4) * 256 + ((k2 & 15) >> 2) * 64 + (k2 & 3)], dn_pre * r);
-            }
             sv_r = dr_pre;
             sv_z = dz_pre;
             sv_n = dn_pre;
             sv_g = dn_pre * r;
+        }
+        {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j.  Quads of gate threads
+            // (units 4u .. 4u+3 of one batch row) gather their values into ONE 16-byte store per gate, as in the forward twin.
+            float q3[3][4];
+#define DS2_QUAD_BCAST(J)                                                                                              \
+    q3[0][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_r), (J) * 0x55, 0xF, 0xF, true));        \
+    q3[1][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_z), (J) * 0x55, 0xF, 0xF, true));        \
+    q3[2][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_g), (J) * 0x55, 0xF, 0xF, true));
+            DS2_QUAD_BCAST(0)
+            DS2_QUAD_BCAST(1)
+            DS2_QUAD_BCAST(2)
+            DS2_QUAD_BCAST(3)
+#undef DS2_QUAD_BCAST
+            if (gate_ok && (jj & 3) == 0) {
+                const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, 2 * slot_floats * 4, 0x00020000);
+                const int sbase = (s & 1) * slot_floats + gbt * nkb * 256 + nn * 4;
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {
+                    const int k = g3 * H + gj;
+                    const f32x4 v = {q3[g3][0], q3[g3][1], q3[g3][2], q3[g3][3]};
+                    store_sc1_b128(rs_w, (sbase + (k >> 4) * 256 + ((k & 15) >> 2) * 64) * 4, __builtin_bit_cast(u32x4, v));
+                }
+            }
         }
         if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
