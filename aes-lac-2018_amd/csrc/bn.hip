@@ -66,6 +66,69 @@ __global__ __launch_bounds__(256) void bn2d_reduce_kernel(const float* __restric
     }
 }
 
+// 16-byte form of the reduction: a (b, c) row of `inner` floats starts at any 4-byte offset, so it is cut into a scalar head
+// (up to 3 elements, to the next 16-byte boundary of the tensor), an aligned float4 body and a scalar tail.  Used when the
+// tensors themselves are 16-byte aligned (torch allocations are).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn2d_reduce_vec_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ mean_invstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int B, int C, int inner,
+                                                              double* __restrict__ part) {
+    const int c = blockIdx.y, p = blockIdx.x, tid = threadIdx.x;
+    const int chunks = (inner + 1023) / 1024;
+    const int items = B * chunks;
+    float mu = 0.f, is = 0.f, ga = 0.f, be = 0.f;
+    if (MODE == 1) {
+        mu = mean_invstd[c];
+        is = mean_invstd[C + c];
+        ga = gamma[c];
+        be = beta[c];
+    }
+    float s0 = 0.f, s1 = 0.f;
+    auto take = [&](float v, float g) {
+        if (MODE == 0) {
+            s0 += v;
+            s1 += v * v;
+        } else {
+            const float xh = (v - mu) * is;
+            const float y = ga * xh + be;
+            const float gm = (y > 0.f && y < 20.f) ? g : 0.f;
+            s0 += gm;
+            s1 += gm * xh;
+        }
+    };
+    for (int it = p; it < items; it += NPART) {
+        const int b = it / chunks, ch = it % chunks;
+        const size_t base = ((size_t)b * C + c) * inner;
+        const int h = min((int)((4 - (base & 3)) & 3), inner);
+        const int nq = (inner - h) >> 2;
+        const int q = ch * 256 + tid;
+        if (q < nq) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + h + 4 * (size_t)q);
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 1) g = *reinterpret_cast<const f32x4*>(dy + base + h + 4 * (size_t)q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) take(v[e], g[e]);
+        }
+        if (ch == 0) {
+            const int tail0 = h + 4 * nq, e = tid < 4 ? tid : tail0 + tid - 4;
+            if ((tid < h) || (tid >= 4 && tid < 8 && e < inner)) take(x[base + e], MODE == 1 ? dy[base + e] : 0.f);
+        }
+    }
+    double d0 = wave_sum_d((double)s0), d1 = wave_sum_d((double)s1);
+    __shared__ double sm[4][2];
+    if ((tid & 63) == 0) {
+        sm[tid >> 6][0] = d0;
+        sm[tid >> 6][1] = d1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        part[((size_t)c * NPART + p) * 2 + 0] = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+        part[((size_t)c * NPART + p) * 2 + 1] = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+    }
+}
+
 // ----------------------------------------------------------------------------- sequence flavour
 // grid (NPART, ceil(F/64)); block = 64 columns x 4 row lanes
 template <int MODE>
@@ -223,6 +286,67 @@ __global__ __launch_bounds__(256) void bn2d_bwd_apply_kernel(const float* __rest
     }
 }
 
+// 16-byte forms of the two elementwise conv-flavour kernels (row = one (b, c) plane; head / aligned body / tail as above)
+template <typename F>
+__device__ __forceinline__ void bn2d_row_vec(size_t base, int inner, F&& f4, int bx, int nbx, int tid) {
+    const int h = min((int)((4 - (base & 3)) & 3), inner);
+    const int nq = (inner - h) >> 2;
+    for (int q = bx * 256 + tid; q < nq; q += nbx * 256) f4(base + h + 4 * (size_t)q, 4);
+    if (bx == 0) {
+        const int tail0 = h + 4 * nq, e = tid < 4 ? tid : tail0 + tid - 4;
+        if ((tid < h) || (tid >= 4 && tid < 8 && e < inner)) f4(base + e, 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn2d_bwd_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ mean_invstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 const float* __restrict__ coef, int C, int inner,
+                                                                 float* __restrict__ dx) {
+    const int bc = blockIdx.y, c = bc % C;
+    const float mu = mean_invstd[c], is = mean_invstd[C + c], ga = gamma[c], be = beta[c];
+    const float mg = coef[c], mgx = coef[C + c];
+    auto one = [&](float xv, float g) {
+        const float xh = (xv - mu) * is;
+        const float yv = ga * xh + be;
+        const float gm = (yv > 0.f && yv < 20.f) ? g : 0.f;
+        return ga * is * (gm - mg - xh * mgx);
+    };
+    bn2d_row_vec((size_t)bc * inner, inner, [&](size_t o, int n) {
+        if (n == 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o), g = *reinterpret_cast<const f32x4*>(dy + o);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = one(xv[e], g[e]);
+            *reinterpret_cast<f32x4*>(dx + o) = r;
+        } else {
+            dx[o] = one(x[o], dy[o]);
+        }
+    }, blockIdx.x, gridDim.x, threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void bn2d_apply_vec_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ mean_invstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int C, int inner,
+                                                             float* __restrict__ y) {
+    const int bc = blockIdx.y, c = bc % C;
+    const float sc = gamma[c] * mean_invstd[C + c];
+    const float sh = beta[c] - mean_invstd[c] * sc;
+    bn2d_row_vec((size_t)bc * inner, inner, [&](size_t o, int n) {
+        if (n == 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + o);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fminf(fmaxf(xv[e] * sc + sh, 0.f), 20.f);
+            *reinterpret_cast<f32x4*>(y + o) = r;
+        } else {
+            y[o] = fminf(fmaxf(x[o] * sc + sh, 0.f), 20.f);
+        }
+    }, blockIdx.x, gridDim.x, threadIdx.x);
+}
+
 __global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
                                                          const float* __restrict__ mean_invstd,
                                                          const float* __restrict__ gamma,
@@ -337,6 +461,7 @@ __global__ __launch_bounds__(256) void bn1d_bwd_apply_vec_kernel(const f32x4* __
     }
 }
 
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline bool vec4_ok(int F, const void* a, const void* b, const void* c, const void* d) {
     return (F & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
 }
@@ -358,9 +483,14 @@ extern "C" int ds2_bn2d_stats(const float* x, int B, int C, int inner, float eps
     DS2_CHECK_ARG(!use_running || (running_mean && running_var));
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)ws;
-    if (!use_running)
-        hipLaunchKernelGGL((bn2d_reduce_kernel<0>), dim3(NPART, C), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
-                           nullptr, B, C, inner, part);
+    if (!use_running) {
+        if (aligned16(x))
+            hipLaunchKernelGGL((bn2d_reduce_vec_kernel<0>), dim3(NPART, C), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                               nullptr, B, C, inner, part);
+        else
+            hipLaunchKernelGGL((bn2d_reduce_kernel<0>), dim3(NPART, C), dim3(256), 0, st, x, nullptr, nullptr, nullptr,
+                               nullptr, B, C, inner, part);
+    }
     hipLaunchKernelGGL(bn_finalize_stats_kernel, dim3(C), dim3(64), 0, st, part, C, (double)B * inner, eps, momentum,
                        use_running, running_mean, running_var, mean_invstd);
     DS2_CHECK_LAUNCH();
@@ -377,8 +507,13 @@ extern "C" int ds2_bn2d_apply_htanh(const float* x, const float* mean_invstd, co
         hipLaunchKernelGGL(bn2d_apply_tbf_kernel, grid, dim3(256), 0, st, x, mean_invstd, gamma, beta, B, C, D, T, y);
     } else {
         const int inner = D * T;
-        dim3 grid(min(ds2_cdiv(inner, 256), 64), B * C);
-        hipLaunchKernelGGL(bn2d_apply_kernel, grid, dim3(256), 0, st, x, mean_invstd, gamma, beta, C, inner, y);
+        if (aligned16(x) && aligned16(y)) {
+            dim3 grid(min(ds2_cdiv(inner, 1024), 64), B * C);
+            hipLaunchKernelGGL(bn2d_apply_vec_kernel, grid, dim3(256), 0, st, x, mean_invstd, gamma, beta, C, inner, y);
+        } else {
+            dim3 grid(min(ds2_cdiv(inner, 256), 64), B * C);
+            hipLaunchKernelGGL(bn2d_apply_kernel, grid, dim3(256), 0, st, x, mean_invstd, gamma, beta, C, inner, y);
+        }
     }
     DS2_CHECK_LAUNCH();
     return DS2_OK;
@@ -393,13 +528,24 @@ extern "C" int ds2_bn2d_htanh_bwd(const float* x, const float* dy, const float* 
     const int inner = D * T;
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)C * NPART * 2);
-    hipLaunchKernelGGL((bn2d_reduce_kernel<1>), dim3(NPART, C), dim3(256), 0, st, x, dy, mean_invstd, gamma, beta, B,
-                       C, inner, part);
+    const bool vec = aligned16(x) && aligned16(dy) && aligned16(dx);
+    if (vec)
+        hipLaunchKernelGGL((bn2d_reduce_vec_kernel<1>), dim3(NPART, C), dim3(256), 0, st, x, dy, mean_invstd, gamma, beta,
+                           B, C, inner, part);
+    else
+        hipLaunchKernelGGL((bn2d_reduce_kernel<1>), dim3(NPART, C), dim3(256), 0, st, x, dy, mean_invstd, gamma, beta, B,
+                           C, inner, part);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, st, part, C, (double)B * inner, dgamma, dbeta,
                        coef);
-    dim3 grid(min(ds2_cdiv(inner, 256), 64), B * C);
-    hipLaunchKernelGGL(bn2d_bwd_apply_kernel, grid, dim3(256), 0, st, x, dy, mean_invstd, gamma, beta, coef, C, inner,
-                       dx);
+    if (vec) {
+        dim3 grid(min(ds2_cdiv(inner, 1024), 64), B * C);
+        hipLaunchKernelGGL(bn2d_bwd_apply_vec_kernel, grid, dim3(256), 0, st, x, dy, mean_invstd, gamma, beta, coef, C,
+                           inner, dx);
+    } else {
+        dim3 grid(min(ds2_cdiv(inner, 256), 64), B * C);
+        hipLaunchKernelGGL(bn2d_bwd_apply_kernel, grid, dim3(256), 0, st, x, dy, mean_invstd, gamma, beta, coef, C, inner,
+                           dx);
+    }
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }

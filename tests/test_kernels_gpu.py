@@ -152,9 +152,10 @@ def test_conv_fwd_bwd(ops, which, bsz, t_in):
 
 
 # ------------------------------------------------------------------------------------------- BN
-def test_bn2d_train_eval_and_backward(ops):
+@pytest.mark.parametrize('bsz,c,d,t', [(3, 32, 21, 57), (2, 32, 1, 3), (2, 32, 4, 8), (1, 32, 61, 131), (5, 32, 1, 2)])
+def test_bn2d_train_eval_and_backward(ops, bsz, c, d, t):
+    """(the planes of the 16-byte kernels start at every 4-byte offset: inner = d * t odd, < 4, a multiple of 4)"""
     rng = np.random.default_rng(20)
-    bsz, c, d, t = 3, 32, 21, 57
     x = torch.from_numpy((3 * rng.standard_normal((bsz, c, d, t)) + 5).astype(np.float32)).requires_grad_(True)
     bn = torch.nn.BatchNorm2d(c)
     with torch.no_grad():
