@@ -127,8 +127,11 @@ def _conv_ref(which, x, w, b):
     return F.conv2d(x, w, b, stride=(2, 1))
 
 
-@pytest.mark.parametrize('which,bsz,t_in', [(1, 2, 121), (1, 3, 64), (2, 2, 66), (2, 1, 43), (1, 1, 301)])
-def test_conv_fwd_bwd(ops, which, bsz, t_in):
+@pytest.mark.parametrize('which,bsz,t_in,wlds', [(1, 2, 121, '0'), (1, 3, 64, '0'), (2, 2, 66, '0'), (2, 1, 43, '0'),
+                                                 (1, 1, 301, '0'), (2, 2, 66, '1'), (2, 3, 139, '1'), (2, 1, 43, '1')])
+def test_conv_fwd_bwd(ops, monkeypatch, which, bsz, t_in, wlds):
+    """(wlds = '1': conv2's forward in the filter-through-LDS form, which large batches select by themselves)"""
+    monkeypatch.setenv('DS2_CONV_WLDS', wlds)
     rng = np.random.default_rng(10 * which + bsz)
     cin, fin, kf = (1, 161, 41) if which == 1 else (32, 61, 21)
     x = torch.from_numpy(rng.standard_normal((bsz, cin, fin, t_in)).astype(np.float32)).requires_grad_(True)
