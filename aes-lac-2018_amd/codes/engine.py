@@ -226,9 +226,20 @@ class Trainer(object):
         m = self.model
         m._ensure_flat()
         gflat = m.flat_grad()
+        # ONE fill of the whole flat gradient, on the side stream beside the forward pass (the step's first side-stream work:
+        # everything the backward pass puts there, and the main stream through the w_hh_t_ready event, is ordered behind
+        # it), instead of a fill in front of every split-K weight-gradient GEMM
+        main = torch.cuda.current_stream()
+        side = m._side_stream(gflat.device) if m.overlap_wgrad else None
+        if side is not None:
+            side.wait_stream(main)
+        prezero = os.environ.get('DS2_PREZERO', '1') != '0'
+        if prezero:
+            with torch.cuda.stream(side if side is not None else main):
+                gflat.zero_()
         acts, sv = m._forward_impl(inputs.contiguous().float(), training=True, need_grad=True)
         costs, d_acts = loss_fn(acts)
-        m._backward_impl(sv, d_acts, gflat, grad_ready=hook)
+        m._backward_impl(sv, d_acts, gflat, grad_ready=hook, prezeroed=prezero)
         return costs, acts
 
     def _bucket_hook(self):

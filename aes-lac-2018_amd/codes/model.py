@@ -337,7 +337,7 @@ class DeepSpeech(nn.Module):
                 hi = o + (q.numel() + 3) // 4 * 4
         return lo, hi
 
-    def _backward_impl(self, sv, d_acts, gflat, grad_ready=None):
+    def _backward_impl(self, sv, d_acts, gflat, grad_ready=None, prezeroed=False):
         """d_acts (T,B,A) -> gradients of every parameter written into ``gflat`` (same layout as the flat params).
 
         ``grad_ready(lo, hi)`` is called as soon as the slice [lo, hi) of ``gflat`` is final (head, then each
@@ -371,6 +371,7 @@ class DeepSpeech(nn.Module):
         # workgroups are not all resident -- the ones that are spin -- until that GEMM has run out of workgroups
         # (measured, rocprofv3 timeline at T = 495: 1.50 ms for the top layer's backward kernel, 1.88-1.94 ms for the four
         # that started behind a 0.38 ms dW_hh GEMM).
+        acc_beta = 1.0 if prezeroed else 0.0
         pending = None
         for li in range(nl - 1, -1, -1):
             rec = sv['layers'][li]
@@ -408,15 +409,17 @@ class DeepSpeech(nn.Module):
                             hp = hout[d].data_ptr() + (0 if d == 0 else bsz * hid * f4)
                             group.append((a_g, 6 * hid, 2 * hid, hp, hid, g_hh[d].data_ptr(), hid))
                             group.append((a_n, 2 * hid, hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4, hid))
+                        # prezeroed: the caller cleared the whole flat gradient with ONE fill (beside the forward pass), so
+                        # the split-K GEMMs add into it instead of each clearing its own output first (45 fills per step)
                         if k <= 6144:                     # (B = 10: +0.6 % on the step; at B = 32, K ~ 16 k, one launch per
-                            ops.gemm_tn_group(group, hid, k)      # problem with its own finer split of K is 7 % faster)
-                        else:
+                            ops.gemm_tn_group(group, hid, k, accumulate=prezeroed)   # problem with its own finer split of K
+                        else:                                                        # is 7 % faster)
                             for a_p, lda, m_p, b_p, ldb, c_p, ldc in group:
-                                ops.gemm_raw(1, 0, m_p, hid, k, a_p, lda, b_p, ldb, c_p, ldc, split_k=0)
-                    else:
+                                ops.gemm_raw(1, 0, m_p, hid, k, a_p, lda, b_p, ldb, c_p, ldc, beta=acc_beta, split_k=0)
+                    elif not prezeroed:
                         g_hh[0].zero_()
                         g_hh[1].zero_()
-                    ops.gemm(dgi, xin.view(rows, n_in), trans_a=True, out=g_ih, split_k=0)  # dW_ih (both dirs)
+                    ops.gemm(dgi, xin.view(rows, n_in), trans_a=True, out=g_ih, beta=acc_beta, split_k=0)  # dW_ih (both dirs)
                 if grad_ready is not None:
                     first = layer.batch_norm.module.weight if layer.batch_norm is not None else r.weight_ih_l0
                     grad_ready(*self._span(first, r.weight_hh_l0_reverse), also_wait=side)

@@ -787,7 +787,7 @@ extern "C" int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
 
 extern "C" int ds2_gemm_f32_tn_group(int count, const float* const* A_host, const int* lda_host, const int* M_host,
                                      const float* const* B_host, const int* ldb_host, float* const* C_host,
-                                     const int* ldc_host, int N, int K, void* stream) {
+                                     const int* ldc_host, int N, int K, int accumulate, void* stream) {
     DS2_CHECK_ARG(count >= 1 && count <= 4 && A_host && lda_host && M_host && B_host && ldb_host && C_host && ldc_host);
     DS2_CHECK_ARG(N > 0 && K > 0);
     GemmGroup g;
@@ -834,7 +834,7 @@ extern "C" int ds2_gemm_f32_tn_group(int count, const float* const* A_host, cons
     if (kper < BK) kper = BK;
     const int nsplit = ds2_cdiv(K, kper);
     hipStream_t st = (hipStream_t)stream;
-    for (int p = 0; p < count; ++p)                              // partial products are accumulated with atomics
+    for (int p = 0; p < count && !accumulate; ++p)               // partial products are accumulated with atomics
         (void)hipMemset2DAsync(g.C[p], (size_t)g.ldc[p] * sizeof(float), 0, (size_t)N * sizeof(float), g.M[p], st);
     dim3 grid(max_tiles, nsplit, count), block(256);
     if (vec)

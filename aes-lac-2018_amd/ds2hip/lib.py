@@ -27,7 +27,7 @@ SIGNATURES = {
     'ds2_wsola_tempo': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'ds2_gain_requantize': (_I, [_P, _P, _P, _I, _P, _P]),
     'ds2_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _F, _I, _P]),
-    'ds2_gemm_f32_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    'ds2_gemm_f32_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ds2_transpose_btf_to_bft': (_I, [_P, _I, _I, _I, _P, _P]),
     'ds2_conv_wt_ws_floats': (_Z, [_I]),
     'ds2_conv_fwd': (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P]),

@@ -201,9 +201,10 @@ def gemm_raw(trans_a, trans_b, m, n, k, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, beta
              split_k)
 
 
-def gemm_tn_group(problems, n, k):
+def gemm_tn_group(problems, n, k, accumulate=False):
     """Up to four TN problems sharing N and K in one launch: ``problems`` = [(a_ptr, lda, m, b_ptr, ldb, c_ptr, ldc), ...]
-    with device pointers as ints.  C_p[m_p, n] = A_p^T B_p (A_p stored k x m_p)."""
+    with device pointers as ints.  C_p[m_p, n] = A_p^T B_p (A_p stored k x m_p); ``accumulate``: C_p += instead (the caller
+    has zeroed C, e.g. the whole flat gradient in one fill)."""
     import ctypes
     cnt = len(problems)
     assert 1 <= cnt <= 4
@@ -211,7 +212,8 @@ def gemm_tn_group(problems, n, k):
     a, lda, m, b, ldb, c, ldc = zip(*problems)
     args = (vp(*a), ip(*lda), ip(*m), vp(*b), ip(*ldb), vp(*c), ip(*ldc))
     fn = lib.load().ds2_gemm_f32_tn_group
-    rc = fn(cnt, *[ctypes.cast(x, ctypes.c_void_p) for x in args], int(n), int(k), torch.cuda.current_stream().cuda_stream)
+    rc = fn(cnt, *[ctypes.cast(x, ctypes.c_void_p) for x in args], int(n), int(k), int(bool(accumulate)),
+            torch.cuda.current_stream().cuda_stream)
     if rc != 0:
         raise lib.Ds2Error(rc, 'ds2_gemm_f32_tn_group failed (%d): %s' % (rc, lib.load().ds2_last_error().decode()))
 

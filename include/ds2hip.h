@@ -87,10 +87,11 @@ int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, 
  * dimension lda_p, B_p stored K x N): the four weight-gradient GEMMs dW_hh of a BiGRU layer -- two directions x
  * {r|z rows, n rows} of dGH^T h_prev, codes/model.py:51-52's backward -- which as separate launches are too small to fill
  * the chip.  The pointer / size arrays are HOST arrays of `count` entries holding device pointers; K is split over
- * workgroups and accumulated with float atomics into C (zero-filled by the call). */
+ * workgroups and accumulated with float atomics into C -- zero-filled by the call, or, with accumulate != 0, added to what
+ * C holds (the caller zeroed the whole flat gradient with one fill: C += A^T B). */
 int ds2_gemm_f32_tn_group(int count, const float* const* A_host, const int* lda_host, const int* M_host,
                           const float* const* B_host, const int* ldb_host, float* const* C_host, const int* ldc_host,
-                          int N, int K, void* stream);
+                          int N, int K, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ conv stack
  * Replaces nn.Conv2d at codes/model.py:143-144 (cuDNN).  Layouts are NCHW with time innermost:

@@ -442,6 +442,12 @@ def test_gemm_tn_group_matches_separate_launches(ops):
     for i in range(4):
         ref = a[i].cpu().numpy()[:, :ms[i]].astype(np.float64).T @ b[i // 2].cpu().numpy().astype(np.float64)
         np.testing.assert_allclose(c[i].cpu().numpy(), ref, rtol=0, atol=2e-6 * np.sqrt(k) * 4)
+    for ci in c:                                                                        # accumulate: C += A^T B
+        ci.fill_(7.0)
+    ops.gemm_tn_group(problems, n, k, accumulate=True)
+    for i in range(4):
+        ref = a[i].cpu().numpy()[:, :ms[i]].astype(np.float64).T @ b[i // 2].cpu().numpy().astype(np.float64) + 7.0
+        np.testing.assert_allclose(c[i].cpu().numpy(), ref, rtol=0, atol=2e-6 * np.sqrt(k) * 4)
     ops.gemm_tn_group(problems[:1], n, k)                                               # a group of one
     ref = a[0].cpu().numpy()[:, :ms[0]].astype(np.float64).T @ b[0].cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(c[0].cpu().numpy(), ref, rtol=0, atol=2e-6 * np.sqrt(k) * 4)
