@@ -347,6 +347,10 @@ class DeepSpeech(nn.Module):
         t, bsz, t1, t_in = sv['t'], sv['bsz'], sv['t1'], sv['t_in']
         rows = t * bsz
         gv = lambda p: self._gview(gflat, p)                                        # noqa: E731
+        # everything the forward pass put on the side stream (the trainer's one fill of ``gflat``, the W_hh transposes) is
+        # complete before the first gradient is written
+        main = torch.cuda.current_stream()
+        main.wait_event(sv['w_hh_t_ready'])
         head = self.fc[0].module
         d2 = d_acts.reshape(rows, ncls)
         ops.gemm(d2, sv['xf'], trans_a=True, out=gv(head[1].weight), split_k=0)               # dW_fc = d^T xf
@@ -361,10 +365,8 @@ class DeepSpeech(nn.Module):
         # The weight-gradient GEMMs of a layer (dW_ih, dW_hh) are not on the chain that feeds the next (lower) layer:
         # chain = d(gi) -> dX GEMM -> BatchNorm backward -> recurrence of the layer below.  They go to a LOW-priority
         # side stream and fill the ~56 CUs the persistent recurrence kernel (200 workgroups) leaves idle.
-        main = torch.cuda.current_stream()
         side = self._side_stream(gflat.device) if self.overlap_wgrad else None
         keepalive = []
-        main.wait_event(sv['w_hh_t_ready'])
         # The side stream's GEMMs of layer l are released only once the recurrence kernel of layer l - 1 has been LAUNCHED
         # (an event recorded on the main stream right in front of it): a low-priority GEMM that is already running when the
         # recurrence arrives keeps back-filling every CU that is only partly free, and the recurrence's 200 whole-CU
