@@ -249,8 +249,14 @@ class Trainer(object):
         comm = self._comm_stream
         gflat = self.model.flat_grad()
 
-        def ready(lo, hi, also_wait=None):
-            comm.wait_stream(torch.cuda.current_stream())
+        def ready(lo, hi, also_wait=None, after=None):
+            # ``after``: an event on the main stream behind which the slice's main-stream writers lie (the backward pass
+            # releases a layer's weight-gradient GEMMs one recurrence launch late: waiting for the whole main stream would
+            # hold the all-reduce back until that recurrence has finished)
+            if after is not None:
+                comm.wait_event(after)
+            else:
+                comm.wait_stream(torch.cuda.current_stream())
             if also_wait is not None:              # weight-gradient GEMMs of this slice run on a side stream
                 comm.wait_stream(also_wait)
             with torch.cuda.stream(comm):

@@ -424,7 +424,10 @@ class DeepSpeech(nn.Module):
                     ops.gemm(dgi, xin.view(rows, n_in), trans_a=True, out=g_ih, beta=acc_beta, split_k=0)  # dW_ih (both dirs)
                 if grad_ready is not None:
                     first = layer.batch_norm.module.weight if layer.batch_norm is not None else r.weight_ih_l0
-                    grad_ready(*self._span(first, r.weight_hh_l0_reverse), also_wait=side)
+                    if gate is not None:
+                        grad_ready(*self._span(first, r.weight_hh_l0_reverse), also_wait=side, after=gate)
+                    else:
+                        grad_ready(*self._span(first, r.weight_hh_l0_reverse), also_wait=side)
 
             if layer.batch_norm is not None:
                 bn = layer.batch_norm.module
