@@ -632,6 +632,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(int M, int N, int K
     }
 }
 
+// zero `rows` rows of N floats with leading dimension ldc: ONE linear fill when the rows are contiguous (the 2-D fill of the
+// runtime runs at ~0.4 TB/s: 38 us for the 16 MB of a dX output against ~8 us for the linear one)
+inline void zero_rows(float* C, int ldc, int N, int rows, hipStream_t st) {
+    if (rows <= 0) return;
+    if (ldc == N)
+        (void)hipMemsetAsync(C, 0, (size_t)rows * N * sizeof(float), st);
+    else
+        (void)hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), rows, st);
+}
+
 // resident slots for the v2 kernel on the current device: 2 workgroups per CU (launch bounds), cached per device
 inline int gemm_slots() {
     static int slots[64] = {0};
@@ -689,8 +699,7 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
             if (sk_units > nslab) sk_units = nslab;
             sk_wgs = ds2_cdiv(sk_total, sk_units);
             const int r0 = (dp / tn) * 256;
-            (void)hipMemset2DAsync(C + (size_t)r0 * ldc, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float),
-                                   M - r0, st);
+            zero_rows(C + (size_t)r0 * ldc, ldc, N, M - r0, st);
         }
         const size_t lds = (size_t)3 * BK * (256 + 4 + 128 + 4) * sizeof(float);
         static bool attr_set[4] = {false, false, false, false};
@@ -728,8 +737,7 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
             }
             sk_wgs = ds2_cdiv(sk_total, sk_units);
             const int r0 = (dp / tn) * BM;                                   // first row that holds a stream-K tile
-            (void)hipMemset2DAsync(C + (size_t)r0 * ldc, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float),
-                                   M - r0, st);
+            zero_rows(C + (size_t)r0 * ldc, ldc, N, M - r0, st);
         }
         dim3 grid(dp + sk_wgs), block(256);
         if (vec0)
@@ -752,7 +760,7 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
     dim3 grid(tm * tn, nsplit), block(256);
     const int atomic = nsplit > 1 ? 1 : 0;
     if (atomic && beta == 0.f)  // partial products are accumulated with atomics: start from zero
-        (void)hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st);
+        zero_rows(C, ldc, N, M, st);
     if (vec)
         hipLaunchKernelGGL((gemm_f32_kernel<AK, BKc, true>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc,
                            beta, tn, kper, atomic, (unsigned int)abytes, (unsigned int)bbytes);
@@ -835,7 +843,7 @@ extern "C" int ds2_gemm_f32_tn_group(int count, const float* const* A_host, cons
     const int nsplit = ds2_cdiv(K, kper);
     hipStream_t st = (hipStream_t)stream;
     for (int p = 0; p < count && !accumulate; ++p)               // partial products are accumulated with atomics
-        (void)hipMemset2DAsync(g.C[p], (size_t)g.ldc[p] * sizeof(float), 0, (size_t)N * sizeof(float), g.M[p], st);
+        zero_rows(g.C[p], g.ldc[p], N, g.M[p], st);
     dim3 grid(max_tiles, nsplit, count), block(256);
     if (vec)
         hipLaunchKernelGGL((gemm_f32_tn_group_kernel<true>), grid, block, 0, st, g, N, K, tn, kper);
