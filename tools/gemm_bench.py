@@ -4,7 +4,7 @@ sys.path.insert(0, 'aes-lac-2018_amd'); sys.path.insert(0, '.')
 import torch, numpy as np
 from ds2hip import ops
 rows = int(os.environ.get('ROWS', '4240'))
-shapes = [('gi   NT', 0, 1, rows, 4800, 800, 1), ('gi0  NT', 0, 1, rows, 4800, 672, 1),
+shapes = [('warm NT', 0, 1, 4096, 4096, 4096, 1), ('gi   NT', 0, 1, rows, 4800, 800, 0), ('gi0  NT', 0, 1, rows, 4800, 672, 0),
           ('dX   NN', 0, 0, rows, 800, 4800, 0), ('dWih TN', 1, 0, 4800, 800, rows, 0),
           ('dWhh TN', 1, 0, 1600, 800, rows, 0), ('dWhn TN', 1, 0, 800, 800, rows, 0),
           ('sq   NT', 0, 1, 4096, 4096, 4096, 1), ('k800 NT', 0, 1, 4096, 4096, 800, 1), ('k800 NT', 0, 1, 4096, 4736, 800, 1),
