@@ -413,9 +413,12 @@ class DeepSpeech(nn.Module):
                             group.append((a_n, 2 * hid, hid, hp, hid, g_hh[d].data_ptr() + 2 * hid * hid * f4, hid))
                         # prezeroed: the caller cleared the whole flat gradient with ONE fill (beside the forward pass), so
                         # the split-K GEMMs add into it instead of each clearing its own output first (45 fills per step)
-                        if k <= 6144:                     # (B = 10: +0.6 % on the step; at B = 32, K ~ 16 k, one launch per
-                            ops.gemm_tn_group(group, hid, k, accumulate=prezeroed)   # problem with its own finer split of K
-                        else:                                                        # is 7 % faster)
+                        # one grouped launch while K = rows is moderate (same-box A/B of the whole step: B = 10 +0.6 %,
+                        # B = 32 (K up to 24 k) +0.6 %, B = 64 x 15 s (K = 47 k) -1.6 %: there one launch per problem, each
+                        # with its own finer split of K, is faster)
+                        if k <= 32768:
+                            ops.gemm_tn_group(group, hid, k, accumulate=prezeroed)
+                        else:
                             for a_p, lda, m_p, b_p, ldb, c_p, ldc in group:
                                 ops.gemm_raw(1, 0, m_p, hid, k, a_p, lda, b_p, ldb, c_p, ldc, beta=acc_beta, split_k=0)
                     elif not prezeroed:
