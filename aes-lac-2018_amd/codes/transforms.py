@@ -58,8 +58,9 @@ class BatchSpectrogram(object):
     clip's frames, percentage = T_i / float(T_max) stored as float32.
     """
 
-    def __init__(self, normalize=True, eps=1e-9, device='cuda'):
+    def __init__(self, normalize=True, eps=1e-9, device='cuda', scale=None):
         self.normalize, self.eps, self.device = normalize, eps, device
+        self.scale = ops.amplitude_scale(scale)      # int16 clips (RawAudioBatch) come out as q * scale: see ToTensor
 
     def __call__(self, wavs, offsets=None):
         if isinstance(wavs, RawAudioBatch):                  # int16 clips (+ drawn augmentation): decode on the device
@@ -67,7 +68,7 @@ class BatchSpectrogram(object):
                 torch.cuda.current_stream().wait_event(wavs.ready)
                 wavs.pcm.record_stream(torch.cuda.current_stream())
             pcm = wavs.pcm if wavs.pcm.is_cuda else wavs.pcm.to(self.device, non_blocking=True)
-            flat, offs = ops.decode_augment(pcm, wavs.offsets, wavs.tempos, wavs.gains_db)
+            flat, offs = ops.decode_augment(pcm, wavs.offsets, wavs.tempos, wavs.gains_db, scale=self.scale)
             lens = [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
         elif offsets is None:
             lens = [int(w.numel()) for w in wavs]
@@ -154,13 +155,24 @@ class ToTensor(object):
     tempo + gain + 16-bit requantisation run on the GPU for the whole minibatch after collate; with ``defer=False``
     (the reference's per-clip contract) the same kernels run at once and a 1-D float tensor comes back.  There is no
     host implementation in the product; ``oracle/audio.py`` specifies the arithmetic (sox itself is absent from the
-    reference tree, so the tempo change is the published WSOLA algorithm with sox's defaults, not sox's samples)."""
+    reference tree, so the tempo change is the published WSOLA algorithm with sox's defaults, not sox's samples).
+
+    ``scale`` is the amplitude contract of ``torchaudio.load`` (reference ``codes/transforms.py:156-161``), which changed
+    between torchaudio versions and which the log1p of the spectrogram is NOT invariant to: ``'unit'`` (default) gives
+    samples in [-1, 1) (int16 / 32768); ``'int32'`` gives int16 * 65536, the un-normalised floats of the mid-2018
+    torchaudio master the released checkpoints were most likely trained with (unpinned: that torchaudio build is not in the
+    reference tree).  With ``defer=True`` the scale is applied by the ``BatchSpectrogram`` that decodes the minibatch.
+
+    The non-deferred path runs device kernels, so it cannot run inside a forked DataLoader worker (the child would have
+    to re-initialise the GPU): it raises there -- use ``defer=True`` (what ``get_default_transforms`` builds) or
+    ``num_workers=0``."""
 
     def __init__(self, sample_rate=16000, augment=False, tempo_range=(0.85, 1.15), gain_range=(-6, 8), defer=False,
-                 device='cuda'):
+                 device='cuda', scale=None):
         self.sample_rate, self.augment = sample_rate, augment
         self.tempo_range, self.gain_range = tempo_range, gain_range
         self.defer, self.device = defer, device
+        self.scale = ops.amplitude_scale(scale)
 
     def _load(self, path):
         import wave
@@ -180,13 +192,27 @@ class ToTensor(object):
             clip.gain_db = float(np.random.uniform(low=self.gain_range[0], high=self.gain_range[1]))
         if self.defer:
             return clip
+        if torch.utils.data.get_worker_info() is not None:
+            raise RuntimeError('ToTensor(defer=False) decodes on the GPU and cannot run in a DataLoader worker process; '
+                               'build the transform with defer=True (the minibatch is then decoded on the device after '
+                               'collate) or use num_workers=0')
         batch = RawAudioBatch.from_clips([clip]).to(self.device)
-        wav, _ = ops.decode_augment(batch.pcm, batch.offsets, batch.tempos, batch.gains_db, self.sample_rate)
+        wav, _ = ops.decode_augment(batch.pcm, batch.offsets, batch.tempos, batch.gains_db, self.sample_rate,
+                                    scale=self.scale)
         return wav.cpu()
 
     def __repr__(self):
         return '{}(sample_rate={}, augment={}, tempo_range={}, gain_range={})'.format(
             self.__class__.__name__, self.sample_rate, self.augment, self.tempo_range, self.gain_range)
+
+
+def waveform_scale(transform):
+    """The amplitude scale of the ``ToTensor`` stage of ``transform`` (1/32768 when there is none): what the
+    ``BatchSpectrogram`` that decodes its deferred clips must apply."""
+    for t in getattr(transform, 'transforms', [transform]):
+        if isinstance(t, ToTensor):
+            return t.scale
+    return ops.UNIT_SCALE
 
 
 _ACCENT_FOLD = {'À': 'A', 'Á': 'A', 'Â': 'A', 'Ã': 'A', 'Ä': 'A', 'Ç': 'C', 'È': 'E', 'É': 'E', 'Ê': 'E', 'Ë': 'E',

@@ -28,11 +28,20 @@ def get_default_transforms(data_dir, config, gpu_frontend=True):
     # gpu_frontend: workers hand on int16 clips + the drawn (tempo, gain); decode, WSOLA, gain and the spectrogram all run
     # on the device after collate.  Otherwise the reference's per-utterance contract (each transform returns a tensor).
     tail = [] if gpu_frontend else [transforms.ToSpectrogram(librosa_compat=True)]
-    train_t = transforms.Compose([transforms.ToTensor(augment=augment, defer=gpu_frontend)] + tail)
-    val_t = transforms.Compose([transforms.ToTensor(augment=False, defer=gpu_frontend)] + tail)
+    scale = audio_scale(config)
+    train_t = transforms.Compose([transforms.ToTensor(augment=augment, defer=gpu_frontend, scale=scale)] + tail)
+    val_t = transforms.Compose([transforms.ToTensor(augment=False, defer=gpu_frontend, scale=scale)] + tail)
     target_t = [transforms.ToLabel(os.path.join(data_dir, 'labels.{}.json'.format(lang)), lang=lang,
                                    remove_accents=(lang != 'pt_BR')) for lang in config.model.langs]
     return train_t, val_t, target_t
+
+
+def audio_scale(config):
+    """``training.audio_scale`` of the JSON config (an addition to the reference's schema; saved with the checkpoint's
+    ``args`` so ``test.py`` decodes the way the model was trained): 'unit' (default), 'int32' or a number -- the amplitude
+    contract of the waveform loader (``transforms.ToTensor``)."""
+    training = config.get('training', {}) if hasattr(config, 'get') else {}
+    return (training or {}).get('audio_scale', None)
 
 
 def get_model(model_dict):
@@ -125,6 +134,12 @@ def get_per_params_lr(model, obj):
     return groups
 
 
+def _is_deferred(transform):
+    """True if no stage of ``transform`` is a waveform loader that decodes on the device per utterance."""
+    stages = getattr(transform, 'transforms', [transform])
+    return all(getattr(t, 'defer', True) for t in stages if isinstance(t, transforms.ToTensor))
+
+
 def get_data_loaders(train_transforms, val_transforms, target_transforms, args, raw_audio=True):
     if not isinstance(target_transforms, (list, tuple)):
         target_transforms = [target_transforms]
@@ -138,9 +153,14 @@ def get_data_loaders(train_transforms, val_transforms, target_transforms, args, 
     else:
         sampler = BucketingSampler(train_set, batch_size=bsz)
     pin = bool(raw_audio) and torch.cuda.is_available()     # page-locked int16 batches: asynchronous uploads one bin ahead
-    train_loader = AudioDataLoader(train_set, num_workers=args.num_workers, batch_sampler=sampler, raw_audio=raw_audio,
+    workers = args.num_workers
+    if workers > 0 and not all(_is_deferred(t) for t in (train_transforms, val_transforms)):
+        # a per-utterance (non-deferred) waveform transform runs device kernels: it cannot live in a forked worker
+        LOG.warning('the waveform transforms decode on the GPU per utterance (defer=False): loading with num_workers=0')
+        workers = 0
+    train_loader = AudioDataLoader(train_set, num_workers=workers, batch_sampler=sampler, raw_audio=raw_audio,
                                    pin_memory=pin)
-    val_loader = AudioDataLoader(val_set, batch_size=bsz, num_workers=args.num_workers, raw_audio=raw_audio,
+    val_loader = AudioDataLoader(val_set, batch_size=bsz, num_workers=workers, raw_audio=raw_audio,
                                  pin_memory=pin)
     if raw_audio and torch.cuda.is_available():
         from ..data import DevicePrefetcher

@@ -11,18 +11,18 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void pcm16_to_float_kernel(const int16_t* __restrict__ pcm, size_t n,
+__global__ __launch_bounds__(256) void pcm16_to_float_kernel(const int16_t* __restrict__ pcm, size_t n, float scale,
                                                              float* __restrict__ out) {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-        out[i] = (float)pcm[i] * (1.0f / 32768.0f);                      // exact: a power of two
+        out[i] = __fmul_rn((float)pcm[i], scale);                        // exact when the scale is a power of two
 }
 
-// y = x * gain[b]; q = clip(rint(y * 32768), -32768, 32767) / 32768   (rint = half to even, as numpy.round)
-__global__ __launch_bounds__(256) void gain_requantize_kernel(const float* __restrict__ x,
-                                                              const int64_t* __restrict__ offsets,
-                                                              const float* __restrict__ gain,
-                                                              float* __restrict__ out) {
+// y = x * gain[b]; q = clip(rint(y * 32768), -32768, 32767); out = q * out_scale   (rint = half to even, as numpy.round)
+// x and out may be the same buffer (in place): no __restrict__ on them
+__global__ __launch_bounds__(256) void gain_requantize_kernel(const float* x, const int64_t* __restrict__ offsets,
+                                                              const float* __restrict__ gain, float out_scale,
+                                                              float* out) {
     const int b = blockIdx.y;
     const int64_t lo = offsets[b], n = offsets[b + 1] - lo;
     const float g = gain[b];
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void gain_requantize_kernel(const float* __res
         const float y = __fmul_rn(x[lo + i], g);
         float q = rintf(__fmul_rn(y, 32768.0f));
         q = fminf(fmaxf(q, -32768.0f), 32767.0f);
-        out[lo + i] = q * (1.0f / 32768.0f);
+        out[lo + i] = __fmul_rn(q, out_scale);
     }
 }
 
@@ -115,19 +115,20 @@ __global__ __launch_bounds__(256) void wsola_kernel(const float* __restrict__ xa
 
 }  // namespace
 
-extern "C" int ds2_pcm16_to_float(const int16_t* pcm, size_t n, float* out, void* stream) {
-    DS2_CHECK_ARG(pcm && out && n > 0);
+extern "C" int ds2_pcm16_to_float(const int16_t* pcm, size_t n, float scale, float* out, void* stream) {
+    DS2_CHECK_ARG(pcm && out && n > 0 && scale > 0.f);
     int blocks = (int)((n + 1023) / 1024);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pcm16_to_float_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pcm, n, out);
+    hipLaunchKernelGGL(pcm16_to_float_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pcm, n, scale, out);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }
 
-extern "C" int ds2_gain_requantize(const float* x, const int64_t* offsets, const float* gain, int B, float* out,
-                                   void* stream) {
-    DS2_CHECK_ARG(x && offsets && gain && out && B > 0 && B <= 65535);
-    hipLaunchKernelGGL(gain_requantize_kernel, dim3(64, B), dim3(256), 0, (hipStream_t)stream, x, offsets, gain, out);
+extern "C" int ds2_gain_requantize(const float* x, const int64_t* offsets, const float* gain, int B, float out_scale,
+                                   float* out, void* stream) {
+    DS2_CHECK_ARG(x && offsets && gain && out && B > 0 && B <= 65535 && out_scale > 0.f);
+    hipLaunchKernelGGL(gain_requantize_kernel, dim3(64, B), dim3(256), 0, (hipStream_t)stream, x, offsets, gain, out_scale,
+                       out);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }

@@ -65,15 +65,36 @@ def wsola_schedule(n, tempo, sample_rate=16000):
     return base[:nseg].astype(np.int32), (nseg + 1) * hop_out + ovl
 
 
-def decode_augment(pcm, offsets, tempos=None, gains_db=None, sample_rate=16000):
+UNIT_SCALE = 1.0 / 32768.0
+
+
+def amplitude_scale(spec):
+    """The waveform amplitude contract (what ``torchaudio.load`` returned, reference ``codes/transforms.py:156-161``):
+    ``'unit'`` / None -> 1/32768 (samples in [-1, 1)); ``'int32'`` -> 65536 (the un-normalised int32-range floats of the
+    mid-2018 torchaudio master: sox hands a 16-bit sample on as a 32-bit one); or a positive number."""
+    if spec is None or spec == 'unit':
+        return UNIT_SCALE
+    if spec == 'int32':
+        return 65536.0
+    scale = float(spec)
+    if not scale > 0:
+        raise ValueError('amplitude scale must be positive, got %r' % (spec,))
+    return scale
+
+
+def decode_augment(pcm, offsets, tempos=None, gains_db=None, sample_rate=16000, scale=UNIT_SCALE):
     """pcm: concatenated int16 clips on the device; offsets: python list (B+1).  Returns (float clips concatenated,
     new offsets list).  ``tempos`` / ``gains_db`` (per clip, or None): the training-set augmentation -- WSOLA tempo,
-    then gain in dB and 16-bit requantisation -- entirely on the device."""
+    then gain in dB and 16-bit requantisation -- entirely on the device.  ``scale``: a sample of value q (int16, or the
+    requantised integer after augmentation) comes out as q * scale (``amplitude_scale``)."""
     import numpy as np
     wav = _empty((pcm.numel(),), pcm)
-    lib.call('ds2_pcm16_to_float', pcm, pcm.numel(), wav)
     if tempos is None and gains_db is None:
+        lib.call('ds2_pcm16_to_float', pcm, pcm.numel(), float(scale), wav)
         return wav, list(offsets)
+    lib.call('ds2_pcm16_to_float', pcm, pcm.numel(), UNIT_SCALE, wav)      # the augmentation works on [-1, 1)
+    if gains_db is None and scale != UNIT_SCALE:
+        gains_db = [0.0] * (len(offsets) - 1)        # the 16-bit output format still applies: requantise, then scale
     bsz = len(offsets) - 1
     lens = [offsets[i + 1] - offsets[i] for i in range(bsz)]
     if tempos is not None:
@@ -95,7 +116,7 @@ def decode_augment(pcm, offsets, tempos=None, gains_db=None, sample_rate=16000):
     if gains_db is not None:
         g = torch.tensor([10.0 ** (float('{:.3f}'.format(v)) / 20.0) for v in gains_db], dtype=torch.float32)
         offs_d = upload_small(torch.tensor(list(offsets), dtype=torch.int64), pcm.device)
-        lib.call('ds2_gain_requantize', wav, offs_d, upload_small(g, pcm.device), bsz, wav)
+        lib.call('ds2_gain_requantize', wav, offs_d, upload_small(g, pcm.device), bsz, float(scale), wav)
     return wav, list(offsets)
 
 

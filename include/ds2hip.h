@@ -55,7 +55,10 @@ int ds2_spectrogram_fwd(const float* wav, const int64_t* wav_offsets, int B, int
  * Replace the per-clip host work of ToTensor (codes/transforms.py:130-224): torchaudio.load of a 16-bit PCM
  * file, and -- for training clips with augment=True -- `sox ... -b 16 -e si <out> tempo T gain G` through a
  * temporary file (:185-218).  The loader ships int16 samples; these run after collate on the whole minibatch.
- *   ds2_pcm16_to_float   out[i] = pcm[i] / 32768                                  (n samples, any concatenation)
+ *   ds2_pcm16_to_float   out[i] = pcm[i] * scale                                  (n samples, any concatenation).  The
+ *                        amplitude scale is torchaudio.load's contract (codes/transforms.py:156-161), which changed between
+ *                        torchaudio versions: 1/32768 gives [-1, 1); 65536 gives the un-normalised int32-range floats of
+ *                        the mid-2018 master (a 16-bit sample read by sox as a 32-bit one).  log1p is not scale invariant.
  *   ds2_wsola_tempo      time-scale change without pitch change (WSOLA, sox's default 82 / 14.68 / 12 ms segment /
  *                        search / overlap -> seg, half = search/2, ovl in samples).  Clip b = x[in_offsets[b] ..
  *                        in_offsets[b+1]) -> out[out_offsets[b] .. out_offsets[b+1]).  The segment schedule is data
@@ -64,13 +67,15 @@ int ds2_spectrogram_fwd(const float* wav, const int64_t* wav_offsets, int B, int
  *                        the schedule: (nseg + 1) * (seg - ovl) + ovl.  Correlations in float64, first maximum wins.
  *                        The algorithm is specified in oracle/audio.py (sox's own implementation is not in the
  *                        reference tree: parity with sox is not claimed).
- *   ds2_gain_requantize  y = x * gain[b]; out = clip(rint(y * 32768), -32768, 32767) / 32768   (the gain in linear
- *                        units, 10^(dB/20); rounding half to even), in place allowed
+ *   ds2_gain_requantize  y = x * gain[b]; out = clip(rint(y * 32768), -32768, 32767) * out_scale   (x in [-1, 1); the gain
+ *                        in linear units, 10^(dB/20); rounding half to even; out_scale as ds2_pcm16_to_float's scale),
+ *                        in place allowed
  */
-int ds2_pcm16_to_float(const int16_t* pcm, size_t n, float* out, void* stream);
+int ds2_pcm16_to_float(const int16_t* pcm, size_t n, float scale, float* out, void* stream);
 int ds2_wsola_tempo(const float* x, const int64_t* in_offsets, const int64_t* out_offsets, const int32_t* bases,
                     const int32_t* base_offsets, int B, int seg, int ovl, int half, float* out, void* stream);
-int ds2_gain_requantize(const float* x, const int64_t* offsets, const float* gain, int B, float* out, void* stream);
+int ds2_gain_requantize(const float* x, const int64_t* offsets, const float* gain, int B, float out_scale, float* out,
+                        void* stream);
 
 /* ------------------------------------------------------------------ generic fp32 GEMM (MFMA)
  * C[M,N] = op(A) * op(B) + beta * C, row-major with leading dimensions.  op(A)=A (M x K, lda) or

@@ -26,17 +26,22 @@ import numpy as np
 SEGMENT_MS, SEARCH_MS, OVERLAP_MS = 82.0, 14.68, 12.0
 
 
-def pcm16_to_float(pcm):
-    """int16 samples -> float32 in [-1, 1)."""
-    return np.asarray(pcm, dtype=np.int16).astype(np.float32) / np.float32(32768.0)
+UNIT_SCALE = 1.0 / 32768.0          # samples in [-1, 1)
+INT32_SCALE = 65536.0               # the un-normalised int32-range floats of the mid-2018 torchaudio master
 
 
-def gain_requantize(y, gain_db):
-    """``gain G`` then the 16-bit signed output format: y * 10^(G/20), round to the nearest int16 step (half to even),
-    clip.  ``gain_db`` is first printed with three decimals, as the sox command line was."""
+def pcm16_to_float(pcm, scale=UNIT_SCALE):
+    """int16 samples -> float32: q * scale, one rounding (none for a power-of-two scale).  The default gives [-1, 1)."""
+    return np.asarray(pcm, dtype=np.int16).astype(np.float32) * np.float32(scale)
+
+
+def gain_requantize(y, gain_db, scale=UNIT_SCALE):
+    """``gain G`` then the 16-bit signed output format: y * 10^(G/20) (y in [-1, 1)), round to the nearest int16 step (half
+    to even), clip -> an integer q; what a loader with amplitude scale ``scale`` then hands on is q * scale.  ``gain_db`` is
+    first printed with three decimals, as the sox command line was."""
     g = np.float32(10.0 ** (float('{:.3f}'.format(gain_db)) / 20.0))
     y = np.asarray(y, dtype=np.float32) * g
-    return np.clip(np.round(y * np.float32(32768.0)), -32768, 32767).astype(np.float32) / np.float32(32768.0)
+    return np.clip(np.round(y * np.float32(32768.0)), -32768, 32767).astype(np.float32) * np.float32(scale)
 
 
 def wsola_params(sample_rate=16000):
@@ -98,6 +103,6 @@ def wsola_tempo(x, tempo, sample_rate=16000):
     return out[:out_pos + ovl]
 
 
-def augment(pcm, tempo, gain_db, sample_rate=16000):
+def augment(pcm, tempo, gain_db, sample_rate=16000, scale=UNIT_SCALE):
     """What a training clip goes through with ``augment=True``: decode, tempo, gain, 16-bit requantisation."""
-    return gain_requantize(wsola_tempo(pcm16_to_float(pcm), tempo, sample_rate), gain_db)
+    return gain_requantize(wsola_tempo(pcm16_to_float(pcm), tempo, sample_rate), gain_db, scale)

@@ -20,11 +20,12 @@ def _pcm(rng, n, amp=0.1):
     return (np.clip(amp * rng.standard_normal(n), -1, 1) * 32767).astype(np.int16)
 
 
-def _run(clips, tempos=None, gains=None):
+def _run(clips, tempos=None, gains=None, scale=None):
     from ds2hip import ops
     offs = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).tolist()
     pcm = torch.from_numpy(np.concatenate(clips)).to('cuda')
-    wav, out_offs = ops.decode_augment(pcm, offs, tempos, gains)
+    kw = {} if scale is None else {'scale': ops.amplitude_scale(scale)}
+    wav, out_offs = ops.decode_augment(pcm, offs, tempos, gains, **kw)
     wav = wav.cpu().numpy()
     return [wav[out_offs[i]:out_offs[i + 1]] for i in range(len(clips))]
 
@@ -34,6 +35,25 @@ def test_decode_is_bit_exact():
     clips = [_pcm(rng, n, 0.5) for n in (1, 7, 16000, 33333)] + [np.asarray([-32768, 32767, 0, -1, 1], np.int16)]
     for got, c in zip(_run(clips), clips):
         assert np.array_equal(got, oa.pcm16_to_float(c))
+
+
+@pytest.mark.parametrize('scale,value', [('unit', oa.UNIT_SCALE), ('int32', oa.INT32_SCALE), (0.37, 0.37)])
+def test_amplitude_scale_is_bit_exact(scale, value):
+    """The waveform amplitude contract of torchaudio.load (reference codes/transforms.py:156-161): [-1, 1) samples, the
+    un-normalised int32-range floats of mid-2018 torchaudio, or any number -- plain decode, the augmented path (WSOLA on
+    [-1, 1), requantised integer * scale) and a tempo-only batch (still requantised at a non-unit scale)."""
+    rng = np.random.default_rng(11)
+    clips = [_pcm(rng, 20000, 0.4), np.asarray([-32768, 32767, 0, -1, 1] * 400, np.int16), _pcm(rng, 5000)]
+    for got, c in zip(_run(clips, scale=scale), clips):
+        assert np.array_equal(got, oa.pcm16_to_float(c, value))
+    tempos, gains = [0.9, 1.1, 1.0], [2.5, 8.0, -3.0]
+    for got, c, t, db in zip(_run(clips, tempos, gains, scale=scale), clips, tempos, gains):
+        assert np.array_equal(got, oa.augment(c, t, db, scale=value))
+    if scale != 'unit':
+        for got, c, t in zip(_run(clips, tempos, None, scale=scale), clips, tempos):
+            assert np.array_equal(got, oa.augment(c, t, 0.0, scale=value))
+    if scale == 'int32':                                   # what sox hands on: the 16-bit sample shifted into 32 bits
+        assert float(_run([np.asarray([-32768, 12345], np.int16)], scale=scale)[0][1]) == 12345.0 * 65536.0
 
 
 @pytest.mark.parametrize('n,tempo', [(16000, 0.9), (50001, 1.137), (240000, 0.85), (240000, 1.15), (1400, 1.1),
@@ -127,3 +147,32 @@ def test_totensor_reference_contract_runs_the_device_kernels(tmp_path):
     np.random.seed(3)
     aug = ToTensor(augment=True)(path)
     assert np.array_equal(aug.numpy(), oa.augment(pcm, t, g))
+
+
+def test_amplitude_scale_through_transforms_config_and_spectrogram(tmp_path):
+    """``training.audio_scale`` of the config reaches both decode paths -- the per-clip ``ToTensor`` and the minibatch
+    ``BatchSpectrogram`` -- and changes the spectrogram (log1p is not scale invariant), exactly as the oracle says."""
+    from codes.transforms import BatchSpectrogram, RawAudioBatch, waveform_scale
+    from codes.utils import training_utils as tu
+    from codes.utils.model_utils import AttrDict
+    _wav_corpus(tmp_path, [20000, 26000])
+    paths = [str(tmp_path / 'u0.wav'), str(tmp_path / 'u1.wav')]
+    pcms = []
+    for p in paths:
+        with wave.open(p, 'rb') as w:
+            pcms.append(np.frombuffer(w.readframes(w.getnframes()), dtype='<i2'))
+    specs = {}
+    for name, value in (('unit', oa.UNIT_SCALE), ('int32', oa.INT32_SCALE)):
+        cfg = AttrDict({'model': AttrDict({'langs': ['en']}), 'training': AttrDict({'audio_scale': name})})
+        train_t, val_t, _ = tu.get_default_transforms(os.path.join(ROOT, 'data'), cfg)
+        assert waveform_scale(val_t) == value
+        clips = [val_t(p) for p in paths]                                   # deferred: int16 clips
+        inputs, pct = BatchSpectrogram(scale=waveform_scale(val_t))(RawAudioBatch.from_clips(clips))
+        ref_in, ref_pct = ospec.batch_log_spectrogram([oa.pcm16_to_float(p, value) for p in pcms])
+        np.testing.assert_allclose(inputs.cpu().numpy(), ref_in, atol=2e-4)
+        assert np.array_equal(pct.numpy(), ref_pct)
+        _, val_cpu, _ = tu.get_default_transforms(os.path.join(ROOT, 'data'), cfg, gpu_frontend=False)
+        per_clip = val_cpu(paths[0])                                        # the reference's per-utterance contract
+        np.testing.assert_allclose(per_clip.numpy(), ospec.log_spectrogram(oa.pcm16_to_float(pcms[0], value)), atol=2e-4)
+        specs[name] = inputs.cpu().numpy()
+    assert float(np.abs(specs['unit'] - specs['int32']).max()) > 0.1       # the two contracts are different inputs

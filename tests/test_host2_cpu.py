@@ -345,3 +345,36 @@ def test_metrics_log_format_and_best_checkpoints(tmp_path):
     assert kept == ['model_best-ckpt_2.pth', 'model_best-ckpt_5.pth']          # CER 10 and 5
     args = cli.build_parser().parse_args(['cfg.json', '--train-manifest', 'a', '--val-manifest', 'b', '--no-sorta-grad'])
     assert args.no_sorta_grad and not args.no_shuffle
+
+
+class _Paths(torch.utils.data.Dataset):
+    def __init__(self, paths, transform):
+        self.paths, self.transform = paths, transform
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, i):
+        return self.transform(self.paths[i]).numel()
+
+
+def test_waveform_loader_in_worker_processes(tmp_path):
+    """The deferred loader (what the training path builds) is pure host work and runs in forked DataLoader workers; the
+    per-utterance form decodes on the GPU and must REFUSE to run in a worker with a clear message instead of dying on a
+    re-initialised device, and ``get_data_loaders`` falls back to ``num_workers=0`` for it."""
+    from codes.transforms import Compose, PCMClip, ToTensor, waveform_scale
+    from codes.utils import training_utils as tu
+    paths = []
+    for i, n in enumerate((1600, 2400, 3200, 4000)):
+        paths.append(str(tmp_path / ('w%d.wav' % i)))
+        _write_wav(paths[-1], 0.1 * np.ones(n, np.float32))
+    got = list(torch.utils.data.DataLoader(_Paths(paths, ToTensor(defer=True)), batch_size=1, num_workers=2))
+    assert [int(g) for g in got] == [1600, 2400, 3200, 4000]
+    assert isinstance(ToTensor(defer=True)(paths[0]), PCMClip)
+    with pytest.raises(RuntimeError, match='cannot run in a DataLoader worker'):
+        list(torch.utils.data.DataLoader(_Paths(paths, ToTensor(defer=False)), batch_size=1, num_workers=2))
+    assert tu._is_deferred(Compose([ToTensor(defer=True)])) and not tu._is_deferred(Compose([ToTensor(defer=False)]))
+    assert waveform_scale(Compose([ToTensor(defer=True, scale='int32')])) == 65536.0
+    assert waveform_scale(Compose([ToTensor(defer=True)])) == 1.0 / 32768.0
+    with pytest.raises(ValueError):
+        ToTensor(scale=-1.0)

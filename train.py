@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, 'aes-lac-2018_amd'))
 from codes.ctc import CTCLoss as warp_CTCLoss  # noqa: E402
 from codes.decoder import GreedyDecoder  # noqa: E402
 from codes.engine import create_evaluator, create_trainer  # noqa: E402
-from codes.transforms import BatchSpectrogram  # noqa: E402
+from codes.transforms import BatchSpectrogram, waveform_scale  # noqa: E402
 from codes.utils import model_utils as mu  # noqa: E402
 from codes.utils import training_utils as tu  # noqa: E402
 from codes.utils.io_utils import AttrDict, expand_values  # noqa: E402
@@ -162,7 +162,7 @@ def main(argv=None):
     train_loader, val_loader = tu.get_data_loaders(train_t, val_t, target_t, args)
     criterion = [warp_CTCLoss()]
     decoder = GreedyDecoder(target_t[0].label_encoder)
-    frontend = BatchSpectrogram(device=device)
+    frontend = BatchSpectrogram(device=device, scale=waveform_scale(train_t))
     for ld in (train_loader, val_loader):            # decode + augmentation + STFT of the NEXT bin run on the prefetch stream
         if hasattr(ld, 'frontend'):
             ld.frontend = frontend
@@ -214,6 +214,8 @@ def main(argv=None):
                 log_step(prev)
             prev = (i, t0, trainer.data_time, loss)
             if main_proc and args.checkpoint_per_batch and iteration % args.checkpoint_per_batch == 0:
+                trainer.flush()      # resolve this step's deferred readback first: a step whose recurrence timed out
+                                     # raises HERE, before its weights can be written to a checkpoint
                 torch.save(payload(epoch, iteration), os.path.join(out_dir, 'model_batch-ckpt_{}.pth'.format(iteration)))
         trainer.flush()
         if prev is not None:
