@@ -331,6 +331,7 @@ def bn1d_bwd(xa, xb, dy, mi, gamma, rows, feat, dgamma, dbeta):
 # ----------------------------------------------------------------------------- GRU recurrence
 GRU_MODE = os.environ.get('DS2_GRU_MODE', 'auto')     # 'auto' | 'persistent' | 'step'
 _sync_ws = {}
+fallback_count = 0                                    # persistent -> per-step fall-backs in this process (bench.py reports it)
 _persistent_off = {}                                  # device key -> reason: that device runs the per-step kernels from now on
 
 
@@ -344,6 +345,14 @@ def _gru_sync_ws(dev, bsz, hid):
     key = _dev_key(dev)
     n = (lib.query('ds2_gru_sync_ws_bytes', bsz, hid) + 3) // 4
     if key not in _sync_ws or _sync_ws[key].numel() < n:
+        old = _sync_ws.get(key)
+        if old is not None:
+            # a larger (B, H) needs a larger workspace: the old one's STICKY timeout flag must not be dropped unread (a
+            # launch that timed out earlier in this step, or before a deferred check, left invalid results behind)
+            word = lib.query('ds2_gru_sync_error_offset') // 4
+            if int(old[word].item()) != 0:
+                raise_async_error()
+            _err_ptr_tables.clear()                   # cached pointer tables name the old workspace's flag
         _sync_ws[key] = torch.zeros(n, dtype=torch.int32, device=dev)
     return _sync_ws[key]
 
@@ -362,8 +371,15 @@ def _use_persistent(dev, bsz, hid):
 
 
 def _disable_persistent(dev, reason):
-    """Same process, later launches: this device uses the launch-per-step kernels from now on."""
+    """Same process, later launches: this device uses the launch-per-step kernels from now on (3x slower at B = 10).
+    ``DS2_GRU_STRICT=1`` (set by bench.py: a benchmark must never report the fall-back's rate as the product's) makes
+    the fall-back an error instead."""
     import logging
+    global fallback_count
+    fallback_count += 1
+    if os.environ.get('DS2_GRU_STRICT', '0') == '1':
+        raise RuntimeError('ds2hip: the persistent GRU kernels would fall back to the launch-per-step kernels on %s (%s) '
+                           'and DS2_GRU_STRICT=1 forbids it' % (dev, reason))
     _persistent_off[_dev_key(dev)] = reason
     logging.getLogger('aes-lac-2018').warning('ds2hip: persistent GRU kernels disabled on %s (%s); using the '
                                               'launch-per-step kernels', dev, reason)

@@ -41,12 +41,8 @@ def test_two_rank_step_matches_ddp_oracle(tmp_path, overlap):
         return all(p.returncode == 0 for p in procs), logs
 
     ok, logs = run_ranks(port)
-    if not ok and any('Timeout (' in log or 'dump_traceback' in log or 'Thread 0x' in log for log in logs):
-        # two processes time-slicing ONE GPU is a configuration only this test has; a rank that stalls there is reported
-        # (the stack it dumped) and the pair is started once more on another port
-        import warnings
-        warnings.warn('a rank of the shared-GPU pair stalled and was restarted:\n' + '\n'.join(logs))
-        ok, logs = run_ranks(port + 211)
+    # no retry: a rank that stalls (it dumps its stacks and exits after 200 s) fails the test with those stacks -- an
+    # intermittent deadlock of the overlapped all-reduce (comm stream, side stream, gate events) must stay visible
     assert ok, '\n'.join(logs)
     want_losses, want_sd, want_params = dc.oracle_ddp_steps(world)
     got = [np.load(o) for o in outs]
