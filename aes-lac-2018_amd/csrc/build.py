@@ -104,6 +104,10 @@ def build(force=False, verbose=False):
     if jobs or force or not os.path.exists(OUT_FI):
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT_FI] +
             [fi_obj if o.endswith(os.sep + 'gru_persist.o') else o for o in objs])
+    # test infrastructure: the stand-in for an RCCL channel kernel (tests/test_coresidency_gpu.py)
+    st_src, st_out = os.path.join(ROOT, 'tests', 'co_resident_kernel.hip'), os.path.join(ROOT, 'tests', 'libco_resident.so')
+    if force or _newer(st_src, st_out, []):
+        run([HIPCC, '--offload-arch=gfx950', '-O2', '-shared', '-fPIC', '-o', st_out, st_src])
     return OUT
 
 

@@ -300,10 +300,8 @@ def test_gru_persistent_mfma_forms_agree_with_step_kernels(ops, monkeypatch, fwd
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=3e-5, rtol=1e-4)
 
 
-def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch):
-    """T = 746 steps of the real layer shape, three times over: every hand-off must be fresh (a stale h would
-    show up as an O(1) difference), and the bounded spins must never trip."""
-    t, bsz, hid = 746, 10, 800
+def _long_sequence_case(ops, monkeypatch, bsz, reps, during=None):
+    t, hid = 746, 800
     torch.manual_seed(1)
     k = 1.0 / hid ** 0.5
     w_hh = ((torch.rand(2, 3 * hid, hid) * 2 - 1) * k).to(DEV)
@@ -311,9 +309,12 @@ def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch):
     gi = torch.randn(t, bsz, 2, 3 * hid).to(DEV)
     d_out = (0.1 * torch.randn(t, bsz, hid)).to(DEV)
     res = {}
-    for mode in ('step', 'persistent', 'persistent', 'persistent'):
+    for mode in ['step'] + ['persistent'] * reps:
         monkeypatch.setattr(ops, 'GRU_MODE', mode)
         g = gi.clone()
+        torch.cuda.synchronize()
+        if during is not None and mode != 'step':
+            during()
         ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
         fwd = (g.clone(), ghn.clone(), hout.clone())
         ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
@@ -326,6 +327,68 @@ def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch):
             for a, b, tol in zip(cur, res, (2e-5, 2e-5, 2e-5, 2e-4, 2e-4)):
                 scale = float(b.abs().max())
                 assert float((a - b).abs().max()) <= tol * max(scale, 1.0)
+    assert not ops._persistent_off                      # no launch fell back to the per-step kernels
+
+
+@pytest.mark.parametrize('bsz', [4, 8, 10, 12, 17, 32, 64])
+def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch, bsz):
+    """T = 746 steps of the real layer shape, repeatedly: every hand-off must be fresh (a stale h would show up as an O(1)
+    difference), and the bounded spins must never trip.  The batch sizes cover every hand-off protocol and kernel form:
+    4 (speculative, one part), 8 (speculative, two parts), 10 (speculative, three parts: the headline), 12 (the last batch
+    size of the speculative protocol), 17 (the first of the two-part 16x16x4 forms, counted protocol), 32 and 64."""
+    _long_sequence_case(ops, monkeypatch, bsz, 3 if bsz <= 12 else 2)
+
+
+_co_resident = {}
+
+
+def co_resident_load(duration_ms=300.0, wgs=32, mbytes=64, iters=10):
+    """Launch the RCCL stand-in (tests/co_resident_kernel.hip: `wgs` long-lived workgroups streaming HBM) back to back on a
+    stream of its own for about ``duration_ms`` of stand-alone time (one launch is timed once per process; beside other
+    work it runs longer); returns (stream, event recorded behind the last launch, buffer)."""
+    import ctypes
+    if 'lib' not in _co_resident:
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libco_resident.so'))
+        lib.co_resident_stream.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.co_resident_stream.restype = ctypes.c_int
+        _co_resident['lib'] = lib
+    lib = _co_resident['lib']
+    buf = torch.zeros(mbytes << 18, dtype=torch.float32, device=DEV)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    key = (wgs, mbytes, iters)
+    if key not in _co_resident:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            assert lib.co_resident_stream(buf.data_ptr(), buf.numel() * 4, wgs, iters, stream.cuda_stream) == 0
+            e0.record(stream)
+            for _ in range(4):
+                assert lib.co_resident_stream(buf.data_ptr(), buf.numel() * 4, wgs, iters, stream.cuda_stream) == 0
+            e1.record(stream)
+        e1.synchronize()
+        _co_resident[key] = e0.elapsed_time(e1) / 4.0
+        print('co-resident stand-in: %d workgroups, %.3f ms per launch stand-alone' % (wgs, _co_resident[key]))
+    launches = max(8, int(duration_ms / _co_resident[key]) + 1)
+    for _ in range(launches):
+        assert lib.co_resident_stream(buf.data_ptr(), buf.numel() * 4, wgs, iters, stream.cuda_stream) == 0
+    done = torch.cuda.Event()
+    done.record(stream)
+    return stream, done, buf
+
+
+@pytest.mark.parametrize('bsz', [8, 10])
+def test_gru_persistent_long_sequence_beside_a_streaming_kernel(ops, monkeypatch, bsz):
+    """The same check with 32 workgroups of another kernel streaming HBM on a third stream the whole time (the condition
+    of a data-parallel step, where RCCL's channel kernels run beside the recurrence, and of tools/interference_probe.py):
+    the speculative hand-off is timing dependent by design, so it is exercised under a neighbour's memory traffic too."""
+    held = []
+
+    def during():
+        held.append(co_resident_load(duration_ms=60.0))
+
+    _long_sequence_case(ops, monkeypatch, bsz, 2, during=during)
+    for _, done, _ in held:
+        done.synchronize()
 
 
 # ------------------------------------------------------------------------------------------- CTC
