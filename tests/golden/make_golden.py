@@ -192,6 +192,27 @@ def cases():
 CASES = dict(cases())
 
 
+def expected_keys(name):
+    """The keys ``run_case`` writes for fixture ``name``, derived without running the reference (the oracle model has the
+    reference's parameter and buffer names: tests/test_oracle_model.py).  tests/test_oracle_misc.py checks every committed
+    fixture against this, so a fixture that was not regenerated after the generator changed cannot go unnoticed."""
+    from oracle.model import OracleDeepSpeech
+    kw = CASES[name]
+    model = OracleDeepSpeech(**kw['model_kwargs'])
+    params = [k for k, _ in model.named_parameters()]
+    keys = {'logits', 'tstride', 'loss_sum', 'out_sizes', 'pct', 'probs'}
+    keys |= {'gnorm_' + k for k in params}
+    keys |= {('grad_' if kw['full_grads'] else 'gsample_') + k for k in params}
+    keys |= {'buf_' + k for k in model.state_dict() if 'running' in k}
+    if kw['full_grads']:
+        keys |= {'inter_conv1', 'inter_conv2'} | {'inter_rnn%d' % i for i in range(kw['model_kwargs'].get('num_rnn_layers', 5))}
+    if kw.get('f64_truth'):
+        keys |= {'gnoise_' + k for k in params}
+    if kw.get('tstride', 1) > 1:
+        keys |= {'argmax', 'argmax2', 'near_tie'}
+    return keys
+
+
 def main():
     """``make_golden.py`` regenerates everything; ``make_golden.py ref_full_b8.npz ...`` only the named fixtures."""
     ref = load_reference_model_module()

@@ -152,3 +152,18 @@ def test_clip_and_nesterov_match_torch():
 def test_ddp_bin_partition():
     assert host.ddp_bins(10, 2, 2, 0) == [[0, 1], [4, 5], [8, 9]]
     assert host.ddp_bins(10, 2, 2, 1) == [[2, 3], [6, 7], [0, 1]]     # wraps to even out
+
+
+def test_golden_fixtures_hold_exactly_the_keys_the_generator_writes():
+    """A fixture that was not regenerated after tests/golden/make_golden.py changed shows up here (ref_tiny
+    and ref_full lacked ``tstride``).  The key set is derived from the generator's case table, not from the reference."""
+    import os
+
+    import numpy as np
+
+    from tests.golden.make_golden import CASES, HERE, expected_keys
+    on_disk = sorted(f for f in os.listdir(HERE) if f.endswith('.npz'))
+    assert on_disk == sorted(CASES), 'fixtures and generator cases differ'
+    for name in CASES:
+        with np.load(os.path.join(HERE, name)) as f:
+            assert set(f.files) == expected_keys(name), (name, sorted(set(f.files) ^ expected_keys(name)))
