@@ -79,7 +79,15 @@ def _freeze_layers(model, freeze_layers):
     return model
 
 
-def finetune_model(model, obj):
+def _resolve(path, data_dir):
+    """A relative path of the config that does not exist from the working directory is looked up under ``--data-dir``
+    (the scripts/*.json of the reference name ``map_en-pt_BR.json`` bare; the file lives in ``data/``)."""
+    if os.path.isabs(path) or os.path.exists(path) or not data_dir:
+        return path
+    return os.path.join(data_dir, path)
+
+
+def finetune_model(model, obj, data_dir=None):
     """Freeze layers and, when the alphabet changes, swap the last FC (training_utils.py:87-122)."""
     freeze_layers = obj.get('freeze_layers', None)
     lang = obj['langs'][0] if 'langs' in obj else obj['lang']
@@ -94,7 +102,8 @@ def finetune_model(model, obj):
         with torch.no_grad():
             torch.nn.init.normal_(new.weight, 0, 0.01)
             if map_fc is not None:
-                pairs = json.load(open(map_fc))
+                LOG.info('\t Mapping FC weights')
+                pairs = json.load(open(_resolve(map_fc, data_dir)))
                 old_idx, new_idx = zip(*pairs)
                 new.weight.index_copy_(0, torch.tensor(new_idx, device=new.weight.device),
                                        old.weight.detach().index_select(0, torch.tensor(old_idx,

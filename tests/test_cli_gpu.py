@@ -147,3 +147,59 @@ def test_trainer_distributed_path_single_rank():
     assert losses == pytest.approx(ref_losses, rel=1e-6)
     # split-K GEMMs and the conv wgrad accumulate with float atomics: the last bits depend on arrival order
     assert float((p - ref_p).abs().max()) < 1e-6
+
+
+def test_finetune_cli_en_checkpoint_to_pt_br_head(tmp_path):
+    """BASELINE configs[4] through the CLI (reference README.md:227-250, codes/utils/training_utils.py:87-122): train a tiny
+    EN model, then ``train.py --continue-from <EN ckpt> scripts/pt_BR-finetune-accents-map-fc.json``: the 29-way head is
+    swapped for the 43-way one, the rows named by data/map_en-pt_BR.json (found through --data-dir) are copied, the run
+    starts as a NEW run (epoch / iteration / optimizer state not resumed), and test.py decodes the result with the pt_BR
+    labels."""
+    _corpus(tmp_path)
+    (tmp_path / 'map_en-pt_BR.json').write_text(open(os.path.join(ROOT, 'data', 'map_en-pt_BR.json')).read())
+    common = ['--data-dir', str(tmp_path), '--train-manifest', str(tmp_path / 'train.csv'), '--val-manifest',
+              str(tmp_path / 'val.csv'), '--local', '--checkpoint', '--num-workers', '0']
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), str(tmp_path / 'tiny.json')] + common +
+                         ['--save-folder', str(tmp_path / 'en')], capture_output=True, text=True, env=dict(os.environ),
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    en_ckpt = tmp_path / 'en' / 'tiny' / 'model_ckpt_2.pth'
+    en = torch.load(str(en_ckpt), map_location='cpu', weights_only=False)
+    cfg = json.load(open(os.path.join(ROOT, 'scripts', 'pt_BR-finetune-accents-map-fc.json')))
+    assert cfg['training']['finetune'] is True and cfg['model']['map_fc'] == 'map_en-pt_BR.json'
+    cfg['model']['name'] = 'ft'
+    cfg['model']['params'] = {'rnn_hidden_size': 32, 'num_rnn_layers': 2}
+    cfg['training'].update(num_epochs=1, batch_size=3)
+    cfg['optimizer']['params']['lr'] = 0.0                # the weights stay what the surgery made them
+    (tmp_path / 'ft.json').write_text(json.dumps(cfg))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), str(tmp_path / 'ft.json')] + common +
+                         ['--continue-from', str(en_ckpt), '--save-folder', str(tmp_path / 'ft')], capture_output=True,
+                         text=True, env=dict(os.environ), timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    log = out.stderr + out.stdout
+    assert 'Changing the last FC layer' in log and 'Mapping FC weights' in log
+    assert 'Start epoch:' not in log                       # a fine-tune run does not resume the EN run's counters
+    ft = torch.load(str(tmp_path / 'ft' / 'ft' / 'model_ckpt_1.pth'), map_location='cpu', weights_only=False)
+    key = 'fc.0.module.1.weight'
+    assert tuple(en['state_dict'][key].shape) == (29, 32) and tuple(ft['state_dict'][key].shape) == (43, 32)
+    pairs = json.load(open(os.path.join(ROOT, 'data', 'map_en-pt_BR.json')))
+    old_idx, new_idx = zip(*pairs)
+    assert torch.equal(ft['state_dict'][key][list(new_idx)], en['state_dict'][key][list(old_idx)])
+    rest = sorted(set(range(43)) - set(new_idx))
+    assert float(ft['state_dict'][key][rest].abs().max()) < 0.1          # the other rows: N(0, 0.01)
+    assert ft['epoch'] == 1 and ft['iteration'] == 2 and len(ft['val_metrics']['cer']) == 1
+    assert ft['optimizer']['param_groups'][0]['lr'] == 0.0 and ft['args']['config']['model']['langs'] == ['pt_BR']
+    for k, v in en['state_dict'].items():                                # lr = 0: the backbone is the EN backbone
+        if k != key and 'running' not in k and 'num_batches' not in k:
+            assert torch.equal(v, ft['state_dict'][k]), k
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'test.py'), '--model-path',
+                          str(tmp_path / 'ft' / 'ft' / 'model_ckpt_1.pth'), '--data-dir', str(tmp_path), '--manifest',
+                          str(tmp_path / 'val.csv'), '--batch-size', '2', '--num-workers', '0', '--verbose'],
+                         capture_output=True, text=True, env=dict(os.environ), timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert 'Test Summary' in out.stdout and 'Average CER' in out.stdout
+    sys.path.insert(0, os.path.join(ROOT, 'aes-lac-2018_amd'))
+    from codes.utils.model_utils import load_model
+    model, _, _, target_t = load_model(str(tmp_path / 'ft' / 'ft' / 'model_ckpt_1.pth'), return_transforms=True,
+                                       data_dir=str(tmp_path))
+    assert model._num_classes == 43 and len(target_t[0].label_encoder.classes_) == 43

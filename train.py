@@ -143,7 +143,7 @@ def main(argv=None):
         model = tu.get_model(args.config.model)
     finetune = bool(args.config.training.get('finetune', False))
     if finetune:
-        model = tu.finetune_model(model, args.config.model)
+        model = tu.finetune_model(model, args.config.model, data_dir=args.data_dir)
     model.to(device)
 
     optimizer = tu.get_optimizer(tu.get_per_params_lr(model, args.config.optimizer), args.config.optimizer)
