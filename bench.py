@@ -39,13 +39,17 @@ def bin_plan(batch_size, num_bins, seed=42, world=1):
     """SURVEY.md 8(d) synthetic corpus, as a PLAN: a list of (bin_seed, durations[batch_size]).
 
     Durations are uniform on [1 s, 15 s], sorted, cut into bins of batch_size (BucketingSampler).  Groups of `world`
-    ADJACENT bins are then shuffled as units, so that the bins the `world` ranks consume in the same step under the
+    ADJACENT bins are the units of the order, so that the bins the `world` ranks consume in the same step under the
     every-world-th rule (codes/sampler.py:119-125) hold clips of similar length (minimises straggling).
-    Audio is only synthesised for the bins a process actually uses (make_bin)."""
+    The order INTERLEAVES short and long groups (shortest, longest, second shortest, second longest, ...): any window
+    of consecutive steps then has the corpus's mean clip length, so the headline does not depend on which `--steps` of
+    the 24 bins get timed (a random shuffle moved it by ~1 %).  Audio is only synthesised for the bins a process
+    actually uses (make_bin)."""
     rng = np.random.default_rng(seed)
     dur = np.sort(rng.uniform(1.0, 15.0, size=batch_size * num_bins))
     bins = [(seed * 100003 + i, dur[i * batch_size:(i + 1) * batch_size]) for i in range(num_bins)]
-    groups = np.random.default_rng(seed + 1).permutation(num_bins // world)   # epoch-2-style shuffled bins
+    ngroups = num_bins // world
+    groups = [g // 2 if g % 2 == 0 else ngroups - 1 - g // 2 for g in range(ngroups)]
     return [bins[g * world + r] for g in groups for r in range(world)]
 
 
@@ -86,13 +90,14 @@ def cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline(plan, budget_s=60.0, full=False):
+def cpu_baseline(plan, budget_s=60.0, full=True):
     """The oracle (stock PyTorch CPU ops, numerically the reference) timed on the host cores: full training steps
     (frontend -> fwd -> CTC -> bwd -> clip -> SGD) on B=10 bins of the SAME workload.  Protocol:
     2 untimed warm-up steps (the shortest bin), then timed steps on five bins spread evenly over the length range
     (0/25/50/75/100 % of the sorted bins), shortest first; value = median of the per-step frames/s.  A CPU step on a
-    median bin takes ~40 s, so the DEFAULT run stops adding bins once `budget_s` of timed work is spent (and says how
-    many of the five it timed); --cpu-full runs all five plus one 8 x 15 s step (BASELINE configs[3]'s per-GPU shape)."""
+    median bin takes ~40 s; the DEFAULT is the complete protocol -- all five bins plus one 8 x 15 s step (BASELINE
+    configs[3]'s per-GPU shape), ~4 min -- and --cpu-quick stops adding bins once `budget_s` of timed work is spent (and
+    says how many of the five it timed)."""
     import torch.nn.functional as F
     from oracle import spectrogram as ospec
     from oracle.model import OracleDeepSpeech
@@ -134,6 +139,8 @@ def cpu_baseline(plan, budget_s=60.0, full=False):
             break
     out = {'value': round(float(np.median(rates)), 1), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
            'cpu_model': cpu_model_name(), 'host_cpus': os.cpu_count(),
+           'threads_note': 'torch default = one thread per physical core; os.cpu_count() threads (two per core, as '
+                           'BASELINE.md suggests) oversubscribes the cores: one short oracle step then takes minutes',
            'per_step_frames_per_s': [round(r, 1) for r in rates],
            'sample': 'oracle (torch CPU conv/BN/GRU/Linear + F.ctc_loss + clip + SGD) full training steps at B=10 on %d of '
                      'the 5 bins spread over the 1-15 s length range (2 untimed warm-up steps on the shortest bin first; '
@@ -182,6 +189,11 @@ def gru_pass_roofline(model, bsz, t):
 
 
 _T0 = time.time()
+
+
+def _fallbacks():
+    from ds2hip import ops
+    return int(ops.fallback_count)
 
 
 def note(msg):
@@ -319,7 +331,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch-size', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-full', action='store_true', help='the complete CPU protocol (5 bins + an 8 x 15 s step; ~5 min)')
+    ap.add_argument('--cpu-full', action='store_true', help='(default since round 3) the complete CPU protocol')
+    ap.add_argument('--cpu-quick', action='store_true', help='stop the CPU protocol after --cpu-budget-s of timed work')
     ap.add_argument('--cpu-budget-s', type=float, default=60.0)
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary shapes and the loader leg')
     ap.add_argument('--fixed-seconds', type=float, default=0.0,
@@ -342,6 +355,9 @@ def main():
         os.environ.setdefault('GPU_MAX_HW_QUEUES', '3')
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X: the product path has no CPU fallback')
+    # a benchmark must never report the launch-per-step fall-back's rate as the product's: a persistent recurrence launch
+    # that cannot run (time-out, grid not co-resident) is an ERROR here, not a logged switch (ds2hip/ops.py)
+    os.environ.setdefault('DS2_GRU_STRICT', '1')
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get('DS2_BENCH_FORCE_DIST') == '1'    # the latter: 1-rank RCCL group, for testing
     if use_dist:
@@ -393,6 +409,60 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dt, frames, osteps = float(tmax[0]), float(t[1]), float(t[2])
+
+    # the same steps with the reference's host synchronisation in EVERY step (codes/engine.py:92) instead of the readback
+    # deferred by one step: SURVEY.md 8(d)'s literal protocol, reported beside the headline
+    def step_sync(i):
+        flat, offs, labels, lens = resident[i % len(resident)]
+        inputs, pct = front(flat, offs)
+        return trainer.update((inputs, labels, pct, lens), defer=False)
+
+    dt_sync, _, _ = timed_steps(lambda i: step_sync(i + args.warmup), args.steps, 0, use_dist)
+    if use_dist:
+        ts = torch.tensor([dt_sync], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        dt_sync = float(ts[0])
+    note('sync-per-step leg done: %.2f ms/step' % (1e3 * dt_sync / args.steps))
+
+    # data-parallel self-diagnosis (every rank takes part): what the collective costs alone, what the step costs with the
+    # per-layer all-reduce overlapped with backward and without, and whether any recurrence launch fell back
+    ddp = None
+    if use_dist:
+        from ds2hip import ops as _ops
+        gflat = model.flat_grad()
+        for _ in range(2):
+            dist.all_reduce(gflat)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(gflat)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 5.0
+        legs = {}
+        for name, flag in (('overlap_1', True), ('overlap_0', False)):
+            trainer.overlap = flag and trainer.distributed
+            dleg, _, _ = timed_steps(step, 8, 2, True)
+            legs[name] = dleg
+        trainer.overlap = trainer.distributed and os.environ.get('DS2_ALLREDUCE_OVERLAP', '1') != '0'
+        tl = torch.tensor([ar_ms, legs['overlap_1'], legs['overlap_0'], float(_ops.fallback_count)], dtype=torch.float64,
+                          device=dev)
+        tl_max = tl.clone()
+        dist.all_reduce(tl_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tl, op=dist.ReduceOp.SUM)
+        ddp = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(),
+               'flat_gradient_bytes': int(gflat.numel() * 4),
+               'allreduce_alone_ms': round(float(tl_max[0]), 3),
+               'allreduce_alone_busbw_GBps': round(2.0 * (world - 1) / max(world, 1) * gflat.numel() * 4 / 1e6
+                                                   / max(float(tl_max[0]), 1e-9), 1),
+               'ms_per_step_overlap_1': round(1e3 * float(tl_max[1]) / 8, 3),
+               'ms_per_step_overlap_0': round(1e3 * float(tl_max[2]) / 8, 3),
+               'persistent_to_step_fallbacks': int(round(float(tl[3]))),
+               'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'),
+               'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES')}
+        note('data-parallel diagnostics done: %s' % json.dumps(ddp))
 
     # BASELINE configs[3] at N > 1: 64 x 15 s over 8 GPUs = 8 clips of 15 s per rank (every rank, same barrier protocol)
     cfg3 = None
@@ -466,6 +536,12 @@ def main():
                                   else 'all %.1f s long' % args.fixed_seconds),
                    'batch_per_gpu': bsz, 'global_batch': bsz * world, 'parallelism': 'dp%d' % world,
                    'last_loss': round(float(loss), 4),
+                   'sync_per_step': {'frames_per_s': round(frames / dt_sync, 1),
+                                     'ms_per_step': round(1e3 * dt_sync / args.steps, 3),
+                                     'note': 'the same steps with a host synchronisation in every step (codes/engine.py:92); '
+                                             'the headline defers each step\'s one readback by one step'},
+                   'persistent_to_step_fallbacks': (_fallbacks() if ddp is None
+                                                    else ddp['persistent_to_step_fallbacks']),
                    'ms_per_step_rank0': {'median': round(1e3 * pct_of(per_sorted, 0.5), 3),
                                          'p10': round(1e3 * pct_of(per_sorted, 0.1), 3),
                                          'p90': round(1e3 * pct_of(per_sorted, 0.9), 3)},
@@ -487,6 +563,8 @@ def main():
     }
     if cfg3 is not None:
         result['config']['config3'] = cfg3
+    if ddp is not None:
+        result['config']['data_parallel'] = ddp
     if world == 1 and not args.no_extras:
         # the other single-GPU BASELINE shapes on the same model, a few steps each
         p32 = bin_plan(32, 8, seed=43)                      # a length-sorted corpus cut into bins of 32, as BucketingSampler does
@@ -499,7 +577,7 @@ def main():
         result['config']['loader'] = loader_leg(trainer, plan, dev)
         note('loader leg done')
     if not args.no_cpu_baseline and world == 1:      # the CPU oracle is timed beside the GPU at N = 1 only
-        result['cpu_baseline'] = cpu_baseline(plan, budget_s=args.cpu_budget_s, full=args.cpu_full)
+        result['cpu_baseline'] = cpu_baseline(plan, budget_s=args.cpu_budget_s, full=not args.cpu_quick)
     if use_dist:
         dist.destroy_process_group()
     sys.stdout.flush()
