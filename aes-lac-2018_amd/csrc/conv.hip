@@ -39,18 +39,25 @@ __global__ __launch_bounds__(256) void conv_wt_layout_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------- forward
-template <int CIN, int KF, int SF, int ST, int PADT, int NT>
+// KS = waves that share one output tile, each taking 1/KS of the filter rows (K split inside the workgroup, partial
+// tiles added through LDS): at B = 10 a layer has only 2.7 tiles per SIMD, too few waves to cover the operand loads' latency
+// (matrix pipes 57 % busy) and a coarse last round; with KS = 2 twice as many waves of half the length are in flight.
+template <int CIN, int KF, int SF, int ST, int PADT, int NT, int KS>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                        const float* __restrict__ bias, int B, int FIN, int TIN,
                                                        int FOUT, int TOUT, int ttiles, float* __restrict__ out) {
+    __shared__ float part[KS > 1 ? (4 / KS) * (KS - 1) * NT * 16 * 64 : 1];
     const int lane = threadIdx.x & 63;
     // readfirstlane: lets hipcc see that everything derived from the wave id is wave-uniform (SGPR buffer
     // descriptors instead of a waterfall loop per load -- cdna_hip_programming.md T20)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const long tile = (long)blockIdx.x * 4 + wave;
+    const int slot = wave / KS, ks = wave % KS;          // tile slot of the workgroup, K share
     const long ntiles = (long)B * ttiles * FOUT;
-    if (tile >= ntiles) return;
+    const long tile_raw = (long)blockIdx.x * (4 / KS) + slot;
+    const bool tile_ok = tile_raw < ntiles;
+    if (KS == 1 && !tile_ok) return;
+    const long tile = tile_ok ? tile_raw : 0;
     const int d = (int)(tile % FOUT);
     const int tt = (int)((tile / FOUT) % ttiles);
     const int b = (int)(tile / ((long)FOUT * ttiles));
@@ -69,11 +76,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 
     // rows r = (ci, kf) of the filter, walked with a one-row register prefetch: the 6 weight pairs and
     // 6*NT input pairs of row r+1 are in flight while the 6*NT MFMAs of row r issue.
-    constexpr int NROWS = CIN * KF;
+    constexpr int NROWS_ALL = CIN * KF;
+    const int r_lo = (NROWS_ALL * ks) / KS, NROWS = tile_ok ? (NROWS_ALL * (ks + 1)) / KS - r_lo : 0;
     const float* wp = wt + lh * 32 + lr;
     const float* inb = in + ((size_t)b * CIN * FIN + (size_t)SF * d) * TIN;
     float a_nxt[KTP / 2], v_nxt[NT][KTP / 2];
-    auto fetch = [&](int r) {
+    auto fetch = [&](int rr) {
+        const int r = r_lo + rr;
         const int ci = r / KF, kf = r - ci * KF;
         // the input row as a buffer resource: out-of-range time steps (the conv padding, the ragged tile end)
         // read back 0 from the hardware range check -- no compare, no select and, above all, no branch around
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
             }
         }
     };
-    fetch(0);
+    if (NROWS > 0) fetch(0);
     for (int r = 0; r < NROWS; ++r) {
         float a_cur[KTP / 2], v_cur[NT][KTP / 2];
 #pragma unroll
@@ -106,6 +115,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < NT; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[kp], v_cur[i][kp], acc[i], 0, 0, 0);
+    }
+    if constexpr (KS > 1) {                              // shares 1 .. KS-1 hand their partial tile to share 0 through LDS
+        float* mine = part + ((size_t)(slot * (KS - 1) + (ks > 0 ? ks - 1 : 0)) * NT * 16) * 64 + lane;
+        if (ks > 0) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(i * 16 + r) * 64] = acc[i][r];
+        }
+        __syncthreads();
+        if (ks > 0 || !tile_ok) return;
+#pragma unroll
+        for (int k2 = 0; k2 < KS - 1; ++k2) {
+            const float* theirs = part + ((size_t)(slot * (KS - 1) + k2) * NT * 16) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] += theirs[(i * 16 + r) * 64];
+        }
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -230,18 +258,22 @@ __global__ __launch_bounds__(512) void conv2_fwd_wlds_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------- conv2 dgrad
 // d_in (B,32,FIN,T1) from d_out (B,32,FOUT,T); kernel (32,32,KF,11), stride (2,1), no padding
-template <int KF, int NT>
+template <int KF, int NT, int KS>
 __global__ __launch_bounds__(256) void conv2_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ wd,
                                                           int B, int FIN, int T1, int FOUT, int T, int ttiles,
                                                           float* __restrict__ din) {
+    __shared__ float part[KS > 1 ? (4 / KS) * (KS - 1) * NT * 16 * 64 : 1];   // K split inside the workgroup: see conv_fwd_kernel
     const int lane = threadIdx.x & 63;
     // readfirstlane: lets hipcc see that everything derived from the wave id is wave-uniform (SGPR buffer
     // descriptors instead of a waterfall loop per load -- cdna_hip_programming.md T20)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const long tile = (long)blockIdx.x * 4 + wave;
+    const int slot = wave / KS, ks = wave % KS;
     const long ntiles = (long)B * ttiles * FIN;
-    if (tile >= ntiles) return;
+    const long tile_raw = (long)blockIdx.x * (4 / KS) + slot;
+    const bool tile_ok = tile_raw < ntiles;
+    if (KS == 1 && !tile_ok) return;
+    const long tile = tile_ok ? tile_raw : 0;
     const int f = (int)(tile % FIN);
     const int tt = (int)((tile / FIN) % ttiles);
     const int b = (int)(tile / ((long)FIN * ttiles));
@@ -261,9 +293,11 @@ __global__ __launch_bounds__(256) void conv2_dgrad_kernel(const float* __restric
     const int kf_first = max(f & 1, f - 2 * (FOUT - 1));
     int nkf = 0;
     for (int kf = kf_first; kf < KF && kf <= f; kf += 2) ++nkf;
-    const int nrows = 32 * nkf;
+    const int nrows_all = 32 * nkf;
+    const int r_lo = (nrows_all * ks) / KS, nrows = tile_ok ? (nrows_all * (ks + 1)) / KS - r_lo : 0;
     float a_nxt[KTP / 2], v_nxt[NT][KTP / 2];
-    auto fetch = [&](int r) {
+    auto fetch = [&](int rr) {
+        const int r = r_lo + rr;
         const int co = r / nkf, kf = kf_first + 2 * (r - co * nkf);
         const int d = (f - kf) >> 1;
         const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
@@ -294,6 +328,25 @@ __global__ __launch_bounds__(256) void conv2_dgrad_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < NT; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[kp], v_cur[i][kp], acc[i], 0, 0, 0);
+    }
+    if constexpr (KS > 1) {
+        float* mine = part + ((size_t)(slot * (KS - 1) + (ks > 0 ? ks - 1 : 0)) * NT * 16) * 64 + lane;
+        if (ks > 0) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(i * 16 + r) * 64] = acc[i][r];
+        }
+        __syncthreads();
+        if (ks > 0 || !tile_ok) return;
+#pragma unroll
+        for (int k2 = 0; k2 < KS - 1; ++k2) {
+            const float* theirs = part + ((size_t)(slot * (KS - 1) + k2) * NT * 16) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] += theirs[(i * 16 + r) * 64];
+        }
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -404,6 +457,111 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------- conv2 wgrad, operands through LDS
+// The direct kernel above feeds every MFMA from two per-lane global loads whose 64 lanes touch 32-64 different cache lines
+// (lane = output channel / filter tap, 32 bytes of a row each): the L1's one-line-per-cycle tag path, not the matrix pipe,
+// bounds it (75 TFLOP/s at B = 10), and the four waves of a workgroup read four different d(out) rows for the same taps.
+// Here a workgroup owns 128 consecutive taps (one 32-tap tile per wave) and walks its (b, d) rows in chunks of 64 time
+// steps: the d(out) chunk (32 channels x 64 steps, shared by the four waves) and the 13 input rows the 128 taps touch
+// (each read at 11 time shifts) are loaded once, coalesced, into LDS (double-buffered, one barrier per chunk); the MFMA
+// operands are conflict-free ds_read_b32.  Partial tiles are added into dW with float atomics as before.
+constexpr int WG_TC = 64, WG_PA = WG_TC + 1, WG_NROW = 13, WG_PB = WG_TC + 11;   // pitches 65 / 75: bank = row * 1 | 11 + t
+__global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                              int B, int FIN, int TIN, int FOUT, int TOUT, int nsplit,
+                                                              float* __restrict__ dw, float* __restrict__ dbias) {
+    constexpr int CIN = 32, KF = 21, KT = 11, SF = 2, NTOT = CIN * KF * KT, NB = WG_NROW * (WG_TC + KT - 1);
+    __shared__ float sA[2][32 * WG_PA];
+    __shared__ float sB[2][WG_NROW * WG_PB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 128, r0 = n0 / KT;
+    const int n = n0 + wave * 32 + lr;
+    const bool n_ok = n < NTOT;
+    const int nn = n_ok ? n : n0;
+    const int boff = (nn / KT - r0) * WG_PB + nn % KT + lh;      // this lane's tap inside the staged input rows (+ k parity)
+    const int aoff = lr * WG_PA + lh;
+    const int tchunks = (TOUT + WG_TC - 1) / WG_TC;
+    const int rows = B * FOUT;
+    const int myrows = (rows - (int)blockIdx.y + nsplit - 1) / nsplit;          // rows blockIdx.y, + nsplit, ...
+    const int nchunks = myrows * tchunks;
+    // staging roles: A -- channel tid / 8, eight steps from (tid % 8) * 8; B -- up to four scalars per thread
+    const int a_co = tid >> 3, a_t = (tid & 7) * 8;
+    float ra[8], rb[4];
+    auto gload = [&](int c) {
+        const int row = blockIdx.y + (c / tchunks) * nsplit, t0 = (c % tchunks) * WG_TC;
+        const int b = row / FOUT, d = row % FOUT;
+        const float* ap = dout + (((size_t)b * 32 + a_co) * FOUT + d) * TOUT + t0 + a_t;
+        if (t0 + a_t + 7 < TOUT) {
+            const f32x4u x0 = *reinterpret_cast<const f32x4u*>(ap), x1 = *reinterpret_cast<const f32x4u*>(ap + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ra[e] = x0[e];
+                ra[4 + e] = x1[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ra[e] = (t0 + a_t + e < TOUT) ? ap[e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int j = idx / (WG_TC + KT - 1), x = idx - j * (WG_TC + KT - 1);
+            const int r = r0 + j;
+            float v = 0.f;
+            if (idx < NB && r < CIN * KF && t0 + x < TIN) {
+                const int ci = r / KF, kf = r - ci * KF;
+                v = in[(((size_t)b * CIN + ci) * FIN + (size_t)SF * d + kf) * TIN + t0 + x];
+            }
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sA[buf][a_co * WG_PA + a_t + e] = ra[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int j = idx / (WG_TC + KT - 1), x = idx - j * (WG_TC + KT - 1);
+            if (idx < NB) sB[buf][j * WG_PB + x] = rb[i];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    if (nchunks > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) gload(c + 1);               // in flight under this chunk's MFMAs
+        const float* pa = sA[buf] + aoff;
+        const float* pb = sB[buf] + boff;
+#pragma unroll 8
+        for (int kp = 0; kp < WG_TC / 2; ++kp) {
+            const float a = pa[2 * kp], v = pb[2 * kp];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc, 0, 0, 0);
+            bsum += a;
+        }
+        if (c + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (n_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            atomicAdd(&dw[(size_t)co * NTOT + n], acc[r]);
+        }
+    }
+    if (blockIdx.x == 0 && wave == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lh == 0) atomicAdd(&dbias[lr], bsum);
+    }
+}
+
 struct ConvGeom {
     int cin, kf, kt, sf, st, padt, fin, fout;
 };
@@ -439,16 +597,31 @@ extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, con
         return (double)((waves + 1023) / 1024) * nt;
     };
     const bool narrow = getenv("DS2_CONV_NT") ? atoi(getenv("DS2_CONV_NT")) == 1 : rounds(1) < rounds(2);
-    const int nt = narrow ? 1 : 2;
+    // conv2: 64 time steps per wave always (half the filter traffic per output), the K split below supplies the waves
+    const int nt = (which == 2 && !getenv("DS2_CONV_NT")) ? 2 : (narrow ? 1 : 2);
     const int ttiles = ds2_cdiv(tout, 32 * nt);
     const long ntiles = (long)B * ttiles * g.fout;
-    dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
-    if (which == 1 && nt == 2)
-        hipLaunchKernelGGL((conv_fwd_kernel<1, 41, 2, 2, 10, 2>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
-                           g.fout, tout, ttiles, out);
-    else if (which == 1)
-        hipLaunchKernelGGL((conv_fwd_kernel<1, 41, 2, 2, 10, 1>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
-                           g.fout, tout, ttiles, out);
+    // K split inside the workgroup (two waves per tile) while the tiles alone give fewer than ~4 waves per SIMD: more waves
+    // in flight to cover the operand loads, and a finer last round.  DS2_CONV_KS = 1 / 2 forces one (A/B timing, tests).
+    // (measured, B = 10, conv2 forward, ms: T_in = 300 0.39 -> 0.27 (KS 4), 500 0.41 -> 0.35 (KS 2), 830 0.56 -> 0.51 (KS 2),
+    // 1501 0.85 -> 0.81 (KS 2); conv1's 41-row tiles are too short to split)
+    int ks = which == 1 ? 1 : (ntiles < 700 ? 4 : (ntiles < 4096 ? 2 : 1));
+    if (getenv("DS2_CONV_KS")) ks = atoi(getenv("DS2_CONV_KS")) == 4 ? 4 : (atoi(getenv("DS2_CONV_KS")) == 2 ? 2 : 1);
+    dim3 grid((unsigned)((ntiles * ks + 3) / 4)), block(256);
+#define DS2_CONV_FWD_GO(C, KF_, SF_, ST_, P_, N_)                                                                       \
+    do {                                                                                                                \
+        if (ks == 4)                                                                                                    \
+            hipLaunchKernelGGL((conv_fwd_kernel<C, KF_, SF_, ST_, P_, N_, 4>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, \
+                               tin, g.fout, tout, ttiles, out);                                                         \
+        else if (ks == 2)                                                                                               \
+            hipLaunchKernelGGL((conv_fwd_kernel<C, KF_, SF_, ST_, P_, N_, 2>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, \
+                               tin, g.fout, tout, ttiles, out);                                                         \
+        else                                                                                                            \
+            hipLaunchKernelGGL((conv_fwd_kernel<C, KF_, SF_, ST_, P_, N_, 1>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, \
+                               tin, g.fout, tout, ttiles, out);                                                         \
+    } while (0)
+    if (which == 1 && nt == 2) DS2_CONV_FWD_GO(1, 41, 2, 2, 10, 2);
+    else if (which == 1) DS2_CONV_FWD_GO(1, 41, 2, 2, 10, 1);
     // filter-through-LDS form from 512 eight-tile workgroups up (two rounds of the chip; measured B = 32: 1.54 -> 1.35 ms,
     // 92 -> 103 TFLOP/s; at B = 10 its 184-342 workgroups leave CUs idle and it ties with the direct kernel);
     // DS2_CONV_WLDS = 0 / 1 forces one (A/B timing, tests)
@@ -470,12 +643,9 @@ extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, con
             hipLaunchKernelGGL((conv2_fwd_wlds_kernel<1>), grid2, dim3(512), lds, st, in, wt_ws, bias, B, g.fin, tin, g.fout,
                                tout, ttiles, out);
     }
-    else if (nt == 2)
-        hipLaunchKernelGGL((conv_fwd_kernel<32, 21, 2, 1, 0, 2>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
-                           g.fout, tout, ttiles, out);
-    else
-        hipLaunchKernelGGL((conv_fwd_kernel<32, 21, 2, 1, 0, 1>), grid, block, 0, st, in, wt_ws, bias, B, g.fin, tin,
-                           g.fout, tout, ttiles, out);
+    else if (nt == 2) DS2_CONV_FWD_GO(32, 21, 2, 1, 0, 2);
+    else DS2_CONV_FWD_GO(32, 21, 2, 1, 0, 1);
+#undef DS2_CONV_FWD_GO
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }
@@ -493,15 +663,24 @@ extern "C" int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, i
         return (double)((waves + 1023) / 1024) * nt;
     };
     const bool narrow = getenv("DS2_CONV_NT") ? atoi(getenv("DS2_CONV_NT")) == 1 : rounds(1) < rounds(2);
-    const int nt = narrow ? 1 : 2;
+    const int nt = getenv("DS2_CONV_NT") ? (narrow ? 1 : 2) : 2;
     const int ttiles = ds2_cdiv(T1, 32 * nt);
     const long ntiles = (long)B * ttiles * 61;
-    if (nt == 2)
-        hipLaunchKernelGGL((conv2_dgrad_kernel<21, 2>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d_out,
-                           wt_ws, B, 61, T1, 21, T, ttiles, d_in);
-    else
-        hipLaunchKernelGGL((conv2_dgrad_kernel<21, 1>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d_out,
-                           wt_ws, B, 61, T1, 21, T, ttiles, d_in);
+    // K split inside the workgroup: as in ds2_conv_fwd.  Measured, B = 10, ms, 32-step tiles unsplit -> 64-step tiles with
+    // four K shares: T_in = 300 0.28 -> 0.25, 830 0.64 -> 0.48, 1100 0.84 -> 0.61, 1501 1.05 -> 0.77
+    // (B = 32 / 64 at T_in = 1000: 2.09 -> 1.56 / 3.93 -> 3.06)
+    int ks = 4;
+    if (getenv("DS2_CONV_KS")) ks = atoi(getenv("DS2_CONV_KS")) == 4 ? 4 : (atoi(getenv("DS2_CONV_KS")) == 2 ? 2 : 1);
+    const dim3 grid((unsigned)((ntiles * ks + 3) / 4));
+#define DS2_DGRAD_GO(N_, K_)                                                                                             \
+    hipLaunchKernelGGL((conv2_dgrad_kernel<21, N_, K_>), grid, dim3(256), 0, st, d_out, wt_ws, B, 61, T1, 21, T, ttiles, d_in)
+    if (nt == 2 && ks == 4) DS2_DGRAD_GO(2, 4);
+    else if (nt == 2 && ks == 2) DS2_DGRAD_GO(2, 2);
+    else if (nt == 2) DS2_DGRAD_GO(2, 1);
+    else if (ks == 4) DS2_DGRAD_GO(1, 4);
+    else if (ks == 2) DS2_DGRAD_GO(1, 2);
+    else DS2_DGRAD_GO(1, 1);
+#undef DS2_DGRAD_GO
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }
@@ -526,6 +705,15 @@ extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, in
     if (which == 1)
         hipLaunchKernelGGL((conv_wgrad_kernel<1, 41, 11, 2, 2, 10>), grid, block, 0, st, in, d_out, B, g.fin, tin,
                            g.fout, tout, nsplit, d_weight, d_bias);
+    else if (!(getenv("DS2_CONV_WGRAD_LDS") && getenv("DS2_CONV_WGRAD_LDS")[0] == '0')) {
+        // operands through LDS: 58 groups of 128 taps x row splits aiming at ~2048 workgroups (DS2_CONV_WGRAD_LDS = 0: the
+        // direct kernel, for A/B timing and tests)
+        const int ngroups = ds2_cdiv(ntot, 128);
+        int split = ds2_cdiv(2048, ngroups);
+        if (split > rows) split = rows;
+        hipLaunchKernelGGL(conv2_wgrad_lds_kernel, dim3(ngroups, split), block, 0, st, in, d_out, B, g.fin, tin, g.fout, tout,
+                           split, d_weight, d_bias);
+    }
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 21, 11, 2, 1, 0>), grid, block, 0, st, in, d_out, B, g.fin, tin,
                            g.fout, tout, nsplit, d_weight, d_bias);
