@@ -487,9 +487,25 @@ __global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __res
     const int nchunks = myrows * tchunks;
     // staging roles: A -- channel tid / 8, eight steps from (tid % 8) * 8; B -- up to four scalars per thread
     const int a_co = tid >> 3, a_t = (tid & 7) * 8;
+    // B staging: element idx = tid + 256 i of the [13 rows][74 steps] window -> (row j, step x): fixed per thread for the launch
+    int b_src[4], b_dst[4], b_x[4];                     // source offset inside a (b, d) image (-1: nothing), LDS offset, step
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int j = idx / (WG_TC + KT - 1), x = idx - j * (WG_TC + KT - 1);
+        const int r = r0 + j, ci = r / KF, kf = r - ci * KF;
+        b_src[i] = (idx < NB && r < CIN * KF) ? (ci * FIN + kf) * TIN + x : -1;
+        b_dst[i] = idx < NB ? j * WG_PB + x : -1;
+        b_x[i] = x;
+    }
     float ra[8], rb[4];
-    auto gload = [&](int c) {
-        const int row = blockIdx.y + (c / tchunks) * nsplit, t0 = (c % tchunks) * WG_TC;
+    int g_row = blockIdx.y, g_tc = 0;                    // (row, time chunk) of the NEXT gload: chunks walk time fastest
+    auto gload = [&]() {
+        const int row = g_row, t0 = g_tc * WG_TC;
+        if (++g_tc == tchunks) {
+            g_tc = 0;
+            g_row += nsplit;
+        }
         const int b = row / FOUT, d = row % FOUT;
         const float* ap = dout + (((size_t)b * 32 + a_co) * FOUT + d) * TOUT + t0 + a_t;
         if (t0 + a_t + 7 < TOUT) {
@@ -503,48 +519,43 @@ __global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 8; ++e) ra[e] = (t0 + a_t + e < TOUT) ? ap[e] : 0.f;
         }
+        const float* bp = in + ((size_t)b * CIN * FIN + (size_t)SF * d) * TIN + t0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int j = idx / (WG_TC + KT - 1), x = idx - j * (WG_TC + KT - 1);
-            const int r = r0 + j;
-            float v = 0.f;
-            if (idx < NB && r < CIN * KF && t0 + x < TIN) {
-                const int ci = r / KF, kf = r - ci * KF;
-                v = in[(((size_t)b * CIN + ci) * FIN + (size_t)SF * d + kf) * TIN + t0 + x];
-            }
-            rb[i] = v;
-        }
+        for (int i = 0; i < 4; ++i) rb[i] = (b_src[i] >= 0 && t0 + b_x[i] < TIN) ? bp[b_src[i]] : 0.f;
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) sA[buf][a_co * WG_PA + a_t + e] = ra[e];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int j = idx / (WG_TC + KT - 1), x = idx - j * (WG_TC + KT - 1);
-            if (idx < NB) sB[buf][j * WG_PB + x] = rb[i];
-        }
+        for (int i = 0; i < 4; ++i)
+            if (b_dst[i] >= 0) sB[buf][b_dst[i]] = rb[i];
     };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float bsum = 0.f;
     if (nchunks > 0) {
-        gload(0);
+        gload();
         lstore(0);
     }
     __syncthreads();
+    const bool sum_bias = blockIdx.x == 0 && wave == 0;  // d(bias) = the d(out) row sums: one wave of the first tap group
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) gload(c + 1);               // in flight under this chunk's MFMAs
+        if (c + 1 < nchunks) gload();                    // in flight under this chunk's MFMAs
         const float* pa = sA[buf] + aoff;
         const float* pb = sB[buf] + boff;
+        if (sum_bias) {
 #pragma unroll 8
-        for (int kp = 0; kp < WG_TC / 2; ++kp) {
-            const float a = pa[2 * kp], v = pb[2 * kp];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc, 0, 0, 0);
-            bsum += a;
+            for (int kp = 0; kp < WG_TC / 2; ++kp) {
+                const float a = pa[2 * kp], v = pb[2 * kp];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc, 0, 0, 0);
+                bsum += a;
+            }
+        } else {
+#pragma unroll 8
+            for (int kp = 0; kp < WG_TC / 2; ++kp)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kp], pb[2 * kp], acc, 0, 0, 0);
         }
         if (c + 1 < nchunks) lstore(buf ^ 1);
         __syncthreads();
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __res
             atomicAdd(&dw[(size_t)co * NTOT + n], acc[r]);
         }
     }
-    if (blockIdx.x == 0 && wave == 0) {
+    if (sum_bias) {
         bsum += __shfl_xor(bsum, 32, 64);
         if (lh == 0) atomicAdd(&dbias[lr], bsum);
     }
@@ -706,11 +717,14 @@ extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, in
         hipLaunchKernelGGL((conv_wgrad_kernel<1, 41, 11, 2, 2, 10>), grid, block, 0, st, in, d_out, B, g.fin, tin,
                            g.fout, tout, nsplit, d_weight, d_bias);
     else if (!(getenv("DS2_CONV_WGRAD_LDS") && getenv("DS2_CONV_WGRAD_LDS")[0] == '0')) {
-        // operands through LDS: 58 groups of 128 taps x row splits aiming at ~2048 workgroups (DS2_CONV_WGRAD_LDS = 0: the
-        // direct kernel, for A/B timing and tests)
+        // operands through LDS: 58 groups of 128 taps x 105 row splits = ~6000 workgroups, four rounds of the six a CU holds
+        // (measured, ms, B = 10 / 32 / 64 / 8 x 15 s: 0.41 / 1.44 / 2.84 / 0.56; the direct kernel: 0.57 / 2.15 / 4.35 / 0.79;
+        // 13 ... 53 splits: 0.42 - 0.49 at B = 10).  DS2_CONV_WGRAD_LDS = 0: the direct kernel, for A/B timing and tests
         const int ngroups = ds2_cdiv(ntot, 128);
-        int split = ds2_cdiv(2048, ngroups);
+        int split = 105;
+        if (getenv("DS2_CONV_WGRAD_SPLIT")) split = atoi(getenv("DS2_CONV_WGRAD_SPLIT"));
         if (split > rows) split = rows;
+        if (split < 1) split = 1;
         hipLaunchKernelGGL(conv2_wgrad_lds_kernel, dim3(ngroups, split), block, 0, st, in, d_out, B, g.fin, tin, g.fout, tout,
                            split, d_weight, d_bias);
     }

@@ -107,19 +107,30 @@ void run(const char* name, Ctl* ctl, float* ring, int floats_per_wg, int by_bloc
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
     Ctl* ctl;
     float* ring;
     hipMalloc(&ctl, sizeof(Ctl));
-    hipMalloc(&ring, (size_t)8 * 2 * 32 * 1024 * 4);
+    // ring memory flavour: default hipMalloc (coarse-grained); "fine" = hipDeviceMallocFinegrained; "uncached" = hipDeviceMallocUncached
+    const char* flavour = argc > 1 ? argv[1] : "coarse";
+    hipError_t err = hipSuccess;
+    if (flavour[0] == 'f') err = hipExtMallocWithFlags((void**)&ring, (size_t)8 * 2 * 32 * 1024 * 4, hipDeviceMallocFinegrained);
+    else if (flavour[0] == 'u') err = hipExtMallocWithFlags((void**)&ring, (size_t)8 * 2 * 32 * 1024 * 4, hipDeviceMallocUncached);
+    else err = hipMalloc(&ring, (size_t)8 * 2 * 32 * 1024 * 4);
+    printf("ring memory: %s (%s)\n", flavour, hipGetErrorString(err));
+    if (err != hipSuccess) return 1;
     for (int fl : {96, 288})
-        for (int work : {0, 200})
+        for (int work : {0})
             for (int delay : {0, 6, 12}) {
                 run<0, 16>("same XCD, plain st, sc1 ld", ctl, ring, fl, 0, work, delay);
                 run<0, 2>("same XCD, plain st, nt ld", ctl, ring, fl, 0, work, delay);
                 run<0, 17>("same XCD, plain st, sc0 sc1 ld", ctl, ring, fl, 0, work, delay);
                 run<1, 16>("same XCD, sc1 st, sc1 ld", ctl, ring, fl, 0, work, delay);
                 run<1, 16>("consecutive blocks, sc1 st, sc1 ld", ctl, ring, fl, 1, work, delay);
+                if (flavour[0] != 'c') {        // coherent memory flavours: plain accesses across XCDs too
+                    run<0, 0>("consecutive blocks, plain st, plain ld", ctl, ring, fl, 1, work, delay);
+                    run<0, 16>("consecutive blocks, plain st, sc1 ld", ctl, ring, fl, 1, work, delay);
+                }
             }
     return 0;
 }
