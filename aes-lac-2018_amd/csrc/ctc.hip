@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ 
     if (lane == 0) lse[row] = mx + logf(s);
 }
 
+// NS = states per thread (ceil(smax / 256), 1 .. 4): a template parameter so that a minibatch of short transcripts does not
+// carry the dead iterations of the longest supported one on the recursion's critical path
+template <int NS>
 __global__ __launch_bounds__(CTC_THREADS) void ctc_alphabeta_kernel(
     const float* __restrict__ acts, const float* __restrict__ lse, const int32_t* __restrict__ labels,
     const int32_t* __restrict__ label_offsets, const int32_t* __restrict__ label_lens,
@@ -82,7 +85,6 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alphabeta_kernel(
         return;
     }
     double* out = (dirn == 0 ? alpha : beta) + (size_t)b * T * smax;
-    constexpr int NS = MAX_S / CTC_THREADS;
     int sym[NS];
     bool skip[NS];
 #pragma unroll
@@ -251,8 +253,16 @@ extern "C" int ds2_ctc_loss_grad(const float* acts, const int32_t* labels, const
     double* ll = beta + (size_t)B * T * smax;
     float* lse = (float*)(ll + B);
     hipLaunchKernelGGL(ctc_lse_kernel, dim3(ds2_cdiv((long)T * B, 4)), dim3(256), 0, st, acts, T * B, A, lse);
-    hipLaunchKernelGGL(ctc_alphabeta_kernel, dim3(B, 2), dim3(CTC_THREADS), 0, st, acts, lse, labels, label_offsets,
-                       label_lens, act_lens, T, B, A, smax, alpha, beta, ll, costs);
+#define DS2_CTC_AB(N_)                                                                                                  \
+    hipLaunchKernelGGL(ctc_alphabeta_kernel<N_>, dim3(B, 2), dim3(CTC_THREADS), 0, st, acts, lse, labels, label_offsets,  \
+                       label_lens, act_lens, T, B, A, smax, alpha, beta, ll, costs)
+    switch (ds2_cdiv(smax, CTC_THREADS)) {
+        case 1: DS2_CTC_AB(1); break;
+        case 2: DS2_CTC_AB(2); break;
+        case 3: DS2_CTC_AB(3); break;
+        default: DS2_CTC_AB(4); break;
+    }
+#undef DS2_CTC_AB
     hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(128), 0, st, acts, lse, labels, label_offsets, label_lens,
                        act_lens, T, B, A, smax, alpha, beta, ll, grad_scale, zero_batch_if_inf, grad);
     DS2_CHECK_LAUNCH();
