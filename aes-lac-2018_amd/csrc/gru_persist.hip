@@ -1184,7 +1184,11 @@ __device__ __forceinline__ float dpp_quad_add(float v) {   // Q = quad_perm sele
 // groups (gate-major: rgi = gate * 2 P + unit group) are dealt, four at a time, to "A sets" (CBSZ = 2) and a last pair to
 // a "B set" (CBSZ = 1) when 6 P is not a multiple of 4:  P = 1: (r0 r1 z0 z1) + (n0 n1);  P = 2: (r0-3) (z0-3) (n0-3);
 // P = 3: (r0-3) (r4 r5 z0 z1) (z2-5) (n0-3) + (n4 n5).
-template <int NGI, int P, int NBT, int PROTO>
+// UGX != 0: UGX unit groups of 4 per workgroup instead of 2 P (the batch parts stay P).  UGX = 5 with P = 3: 20 units x 40
+// slices x 3 parts x 2 directions = 240 workgroups -- the forward pass has the chip to itself, so it can take 240 CUs where
+// the backward pass leaves 52 to the weight-gradient GEMMs; 15 row groups = (r0-3) (r4 z0 z1 z2) (z3 z4 n0 n1) (n2 n3 n4 -):
+// the last A set's fourth block multiplies zeros (16 MFMAs per k instead of 18: 2.99 -> 2.9 us per step at B = 10).
+template <int NGI, int P, int NBT, int PROTO, int UGX = 0>
 __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        float* __restrict__ hout,
                                                                        const float* __restrict__ w_hh,
@@ -1193,8 +1197,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     // [local batch row][gate row = gate * UNITS + unit][FWD4_PITCH partials]
     extern __shared__ __attribute__((aligned(16))) float red4[];
     __shared__ int abort_flag;
-    constexpr int UG = 2 * P, UNITS = 8 * P, NRGI = 6 * P, ROWS = 3 * UNITS;
-    constexpr int NA = NRGI / 4, NBS = (NRGI % 4) / 2;
+    constexpr int UG = UGX ? UGX : 2 * P, UNITS = 4 * UG, NRGI = 3 * UG, ROWS = 3 * UNITS;
+    constexpr int NA = (NRGI % 4 == 3) ? NRGI / 4 + 1 : NRGI / 4, NBS = (NRGI % 4 == 2) ? 1 : 0;
+    static_assert(NRGI % 4 != 1, "a single left-over row group is not dealt");
     constexpr int CGW = P == 1 ? CGC : (P == 2 ? 2 : 1);   // batch quads per chunk (register budget)
     constexpr int RPP = (NWP * 64) / (4 * UNITS);          // batch rows the gate role covers per pass (16, 8, 5)
 
@@ -1223,7 +1228,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     f32x4 wA[NA][NGI][4], wB[NBS > 0 ? NBS : 1][NGI][2];
     auto weight_row = [&](int rgi) {
         const int gate = rgi / UG, unit = j0 + 4 * (rgi % UG) + li;
-        return unit < H ? w_hh + ((size_t)dir * 3 * H + (size_t)gate * H + unit) * H : nullptr;
+        return (rgi < NRGI && unit < H) ? w_hh + ((size_t)dir * 3 * H + (size_t)gate * H + unit) * H : nullptr;
     };
 #pragma unroll
     for (int gi = 0; gi < NGI; ++gi) {
@@ -1381,7 +1386,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                         float* rec = red4 + (size_t)((cg * 4 + i) * ROWS) * FWD4_PITCH + partial;
 #pragma unroll
                         for (int a = 0; a < NA; ++a)
-                            rec[(4 * (4 * a + q) + li) * FWD4_PITCH] = accA[a][ci][0][i] + accA[a][ci][1][i];
+                            if (4 * (a + 1) <= NRGI || 4 * a + q < NRGI)       // (the padding block of a partial last set)
+                                rec[(4 * (4 * a + q) + li) * FWD4_PITCH] = accA[a][ci][0][i] + accA[a][ci][1][i];
                         if constexpr (NBS > 0) {
                             const float vb = dpp_row_shr_add<8>(accB[0][ci][0][i] + accB[0][ci][1][i]);
                             if (q >= 2) rec[(4 * (4 * NA + (q & 1)) + li) * FWD4_PITCH] = vb;
@@ -1594,22 +1600,23 @@ bool launch_bwd_persistent_p2(float* G, float* ghn, const float* hout, const flo
     return false;
 }
 
-template <int P, int NBT, int PROTO>
+template <int P, int NBT, int PROTO, int UGX = 0>
 bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
                             int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3};
     const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(H, 64), NWP), opts, 3);
-    dim3 grid(ds2_cdiv(H, 8 * P), 2, P), block(NWP * 64);
+    constexpr int UNITS = UGX ? 4 * UGX : 8 * P;
+    dim3 grid(ds2_cdiv(H, UNITS), 2, P), block(NWP * 64);
     const int ncg = (ds2_cdiv(B, P) + 3) / 4;
-    const size_t lds = (size_t)ncg * 4 * 24 * P * FWD4_PITCH * sizeof(float);
+    const size_t lds = (size_t)ncg * 4 * 3 * UNITS * FWD4_PITCH * sizeof(float);
 #define DS2_FWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, P, NBT, PROTO>),           \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_fwd_persistent4_kernel<K, P, NBT, PROTO, UGX>),           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
-        if (!grid_is_coresident(&gru_fwd_persistent4_kernel<K, P, NBT, PROTO>, grid, lds)) return false;                \
-        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, P, NBT, PROTO>), grid, block, lds, st, G, ghn, hout, w_hh, sync,    \
+        if (!grid_is_coresident(&gru_fwd_persistent4_kernel<K, P, NBT, PROTO, UGX>, grid, lds)) return false;                \
+        hipLaunchKernelGGL((gru_fwd_persistent4_kernel<K, P, NBT, PROTO, UGX>), grid, block, lds, st, G, ghn, hout, w_hh, sync,    \
                            ring, T, B, H, dbg, spec_timing(0));                                                                  \
         return true;
     switch (ngi) {
@@ -1787,6 +1794,12 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     (proto != 0 ? launch_fwd_persistent4<P_, N_, 2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)                \
                 : launch_fwd_persistent4<P_, N_, 0>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
         const int proto = handoff_protocol(bper);
+        // three parts, one batch quad each, speculative hand-off (B = 9 .. 12): 20-unit slices on 240 CUs when they fit
+        const char* wide = getenv("DS2_GRU_FWD_WIDE");
+        if (parts == 3 && !two && proto != 0 && (wide ? wide[0] == '1' : true) && H % 4 == 0 &&
+            6 * ds2_cdiv(H, 20) <= max_persistent_wgs() && 6 * ds2_cdiv(H, 20) > 6 * ds2_cdiv(H, 24))
+            ok = launch_fwd_persistent4<3, 1, 2, 5>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+        else
         if (parts == 1) ok = two ? DS2_FWD4_GO(1, 2) : DS2_FWD4_GO(1, 1);
         else if (parts == 2) ok = two ? DS2_FWD4_GO(2, 2) : DS2_FWD4_GO(2, 1);
         else ok = two ? DS2_FWD4_GO(3, 2) : DS2_FWD4_GO(3, 1);

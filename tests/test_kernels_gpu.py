@@ -376,6 +376,13 @@ def co_resident_load(duration_ms=300.0, wgs=32, mbytes=64, iters=10):
     return stream, done, buf
 
 
+def test_gru_persistent_long_sequence_narrow_forward_form(ops, monkeypatch):
+    """B = 9 .. 12 runs the forward recurrence on 240 CUs (20-unit slices) by default; the 24-unit form on 204 CUs that the
+    backward pass uses stays selectable (DS2_GRU_FWD_WIDE=0) and is checked here."""
+    monkeypatch.setenv('DS2_GRU_FWD_WIDE', '0')
+    _long_sequence_case(ops, monkeypatch, 10, 2)
+
+
 @pytest.mark.parametrize('bsz', [8, 10])
 def test_gru_persistent_long_sequence_beside_a_streaming_kernel(ops, monkeypatch, bsz):
     """The same check with 32 workgroups of another kernel streaming HBM on a third stream the whole time (the condition
