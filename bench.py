@@ -514,7 +514,7 @@ def main():
     # HBM-side bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of the same shape whose
     # summary is committed under profiles/ (PMC collection cannot run inside this process); the file is named below
     traffic, traffic_src = None, None
-    for name in ('r02_traffic.json', 'r01_traffic.json'):
+    for name in ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
