@@ -159,6 +159,15 @@ __device__ __forceinline__ bool validate_fragments(f32x4 (&bf)[NCI][NGI], LoadFr
                                                    int& nretry) {
     bool retried = false;
     unsigned long long t_retry = 0;
+    if constexpr (NCI * NGI <= 2) {   // the common case -- every fragment already holds payload -- costs ONE ballot (with the
+                                      // backward kernel's five fragments the joint test measured 0.05 us per step SLOWER)
+        bool stale = false;
+#pragma unroll
+        for (int gi = 0; gi < NGI; ++gi)
+#pragma unroll
+            for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][gi]);
+        if (!__any(stale)) goto validated;
+    }
     for (;;) {
         asm volatile("" ::: "memory");                            // (keeps re-loads from being hoisted or merged)
         bool any = false;
@@ -183,6 +192,7 @@ __device__ __forceinline__ bool validate_fragments(f32x4 (&bf)[NCI][NGI], LoadFr
             break;
         }
     }
+validated:
     if (((spec >> 16) & 1) && first_chunk) {
         if (retried) {
             spec_delay = min(spec_delay + ((spec >> 18) & 3), 63);
@@ -192,6 +202,10 @@ __device__ __forceinline__ bool validate_fragments(f32x4 (&bf)[NCI][NGI], LoadFr
             spec_delay = max(spec_delay - 1, 0);
         }
     }
+    // wave-uniform by construction (every decision above is a ballot): tell the compiler, so that the first-attempt sleep
+    // and this bookkeeping are scalar code instead of exec-masked vector loops
+    spec_delay = __builtin_amdgcn_readfirstlane(spec_delay);
+    spec_clean = __builtin_amdgcn_readfirstlane(spec_clean);
     return retried;
 }
 
