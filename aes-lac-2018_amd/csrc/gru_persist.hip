@@ -1066,7 +1066,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                         }
                 }
             };
-            if (!DS2_DBG(dbg, 2)) {
+            if (SPEC && ncg == 1 && !DS2_DBG(dbg, 2)) {
+                // the speculative protocol's case -- ONE batch quad per workgroup -- without the chunk loop's bookkeeping
+                chunk(0, std::integral_constant<int, 1>{});
+            } else if (!DS2_DBG(dbg, 2)) {
                 const int nfull = ncg / CGW, tail = ncg - nfull * CGW;
 #pragma unroll 1
                 for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGW>{});
@@ -1082,7 +1085,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         DS2_TICK(3);
         __syncthreads();
         DS2_TICK(4);
-        if (CAN && abort_flag) return;                  // a wave gave up on a payload that never came (bounded re-loads)
+        // a wave gave up on a payload that never came (bounded re-loads): the flag is READ here, with the partial sums, and
+        // TESTED before anything leaves the workgroup -- its LDS round trip is not a separate stop on the step's chain
+        const int aborted = CAN ? abort_flag : 0;
         if (gate_ok) {
             if (s > 0) {
                 const int rg = jj >> 2, rr = jj & 3, cg = nn >> 2, bj = nn & 3;
@@ -1108,6 +1113,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             sv_n = dn_pre;
             sv_g = dn_pre * r;
         }
+        if (aborted) return;
         if (CAN) {
             // Hand-off stores of the speculative protocol: four neighbouring gate threads (units 4q .. 4q+3 of one batch row:
             // adjacent lanes, 16 contiguous bytes of the ring) hand their values to the first of them, which issues ONE
@@ -1409,7 +1415,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                     }
                 }
             };
-            if (!DS2_DBG(dbg, 2)) {
+            if (SPEC && ncg == 1 && !DS2_DBG(dbg, 2)) {
+                // the speculative protocol's case -- ONE batch quad per workgroup -- without the chunk loop's bookkeeping
+                chunk(0, std::integral_constant<int, 1>{});
+            } else if (!DS2_DBG(dbg, 2)) {
                 const int nfull = ncg / CGW, tail = ncg - nfull * CGW;
 #pragma unroll 1
                 for (int c = 0; c < nfull; ++c) chunk(c, std::integral_constant<int, CGW>{});
@@ -1423,7 +1432,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
             }
         }
         __syncthreads();
-        if (CAN && abort_flag) return;                  // a wave gave up on a payload that never came (bounded re-loads)
+        // a wave gave up on a payload that never came (bounded re-loads): read with the partial sums, tested before the
+        // stores (see the backward kernel)
+        const int aborted = CAN ? abort_flag : 0;
         // speculative protocol: the previous step's stores (a step old) are complete before this step's payload goes out
         if (SPEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1452,7 +1463,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 const float n = fast_tanh(gi_n[bt] + r * gh_n);
                 const float h = (1.f - z) * n + z * hp[bt];
                 hp[bt] = h;
-                if (gpart == 0) {
+                if (gpart == 0 && !aborted) {
                     // (speculative protocol, fault-injection builds: workgroup 0 'loses' its payload of step 2)
                     const bool lose = SPEC && DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
                     if (!lose) store_sc1(my_ring + (size_t)scur * slot_floats + hoff[bt], CAN ? not_canary(h) : h);
@@ -1463,6 +1474,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 sv_g[bt] = gh_n;
             }
         }
+        if (aborted) return;
         if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
         if (SPEC && (spec & (1 << 17))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // self-timed: see spec_timing()
         sprev = scur;
