@@ -1120,10 +1120,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             // 16-byte write-through store per gate and ONE 16-byte canary store into the slot two ahead: 6 store instructions
             // of a quarter of the lanes instead of 12 of all of them.  (UNITS and H are multiples of 4: quads never straddle.)
             float q[3][4];
+            // (the canary pattern is filtered out of the three OWN values, before they are handed around: 3 tests, not 12)
+            const float pay_r = not_canary(sv_r), pay_z = not_canary(sv_z), pay_g = not_canary(sv_g);
 #define DS2_QUAD_BCAST(J)                                                                                              \
-    q[0][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_r), (J) * 0x55, 0xF, 0xF, true));         \
-    q[1][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_z), (J) * 0x55, 0xF, 0xF, true));         \
-    q[2][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_g), (J) * 0x55, 0xF, 0xF, true));
+    q[0][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pay_r), (J) * 0x55, 0xF, 0xF, true));        \
+    q[1][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pay_z), (J) * 0x55, 0xF, 0xF, true));        \
+    q[2][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pay_g), (J) * 0x55, 0xF, 0xF, true));
             DS2_QUAD_BCAST(0)
             DS2_QUAD_BCAST(1)
             DS2_QUAD_BCAST(2)
@@ -1143,7 +1145,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 const bool lose = SPEC && DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
 #pragma unroll
                 for (int g3 = 0; g3 < 3; ++g3) {
-                    const f32x4 v = {not_canary(q[g3][0]), not_canary(q[g3][1]), not_canary(q[g3][2]), not_canary(q[g3][3])};
+                    const f32x4 v = {q[g3][0], q[g3][1], q[g3][2], q[g3][3]};
                     if (!lose) store_sc1_b128(rs_w, (sbase + hos[g3]) * 4, __builtin_bit_cast(u32x4, v));
                     store_sc1_b128(rs_w, (nbase + hos[g3]) * 4, can4);
                 }
