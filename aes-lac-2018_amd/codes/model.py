@@ -383,6 +383,20 @@ class DeepSpeech(nn.Module):
             w_ih = self._pair(r.weight_ih_l0, r.weight_ih_l0_reverse)
             w_hh_t = sv['w_hh_t'][li]                                               # transposed during forward
             gates, ghn, hout = rec['gates'], rec['ghn'], rec['hout']
+            # The dX GEMM below splits K and adds its partial products with atomics, so its output must start from zero: the
+            # fill (16 MB) is issued on the SIDE stream in front of the recurrence launch and runs beside it, instead of on
+            # the chain behind it (where, sharing the chip with the side stream's dW_ih GEMM, it took ~30 us per layer)
+            dx_buf, dx_ready = None, None
+            if side is not None:
+                dx_buf = torch.empty((rows, n_in), dtype=gates.dtype, device=gates.device)
+                dx_buf.record_stream(side)
+                alloc_ev = torch.cuda.Event()
+                alloc_ev.record(main)
+                side.wait_event(alloc_ev)
+                with torch.cuda.stream(side):
+                    dx_buf.zero_()
+                    dx_ready = torch.cuda.Event()
+                    dx_ready.record(side)
             if pending is not None:
                 gate = torch.cuda.Event()
                 gate.record(main)
@@ -391,7 +405,11 @@ class DeepSpeech(nn.Module):
                 pending(gate)
                 pending = None
             dgi = gates.view(rows, 6 * hid)
-            dxin = ops.gemm(dgi, w_ih, split_k=0)                                   # (rows, n_in): on the chain
+            if dx_buf is not None:
+                main.wait_event(dx_ready)
+                dxin = ops.gemm(dgi, w_ih, out=dx_buf, beta=1.0, split_k=0)         # (rows, n_in): on the chain
+            else:
+                dxin = ops.gemm(dgi, w_ih, split_k=0)
             g_hh = (gv(r.weight_hh_l0), gv(r.weight_hh_l0_reverse))
             g_ih = self._pair_view(gflat, r.weight_ih_l0, r.weight_ih_l0_reverse)
 
