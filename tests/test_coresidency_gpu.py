@@ -34,33 +34,61 @@ def _run(mode, batches, monkeypatch, load):
     from codes.model import DeepSpeech
     from ds2hip import ops
     monkeypatch.setattr(ops, 'GRU_MODE', mode)
-    torch.manual_seed(7)
-    model = DeepSpeech().to('cuda')                                      # the full 5 x BiGRU-800 model
-    opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
-    trainer = Trainer(model, opt, device='cuda', max_norm=400)
-    assert trainer._fused
-    trainer.update(batches[0])                                           # warm-up (allocations, first-launch checks)
-    torch.cuda.synchronize()
+
+    def fresh():
+        torch.manual_seed(7)
+        model = DeepSpeech().to('cuda')                                  # the full 5 x BiGRU-800 model
+        opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
+        trainer = Trainer(model, opt, device='cuda', max_norm=400)
+        assert trainer._fused
+        return model, trainer
+
+    fresh()[1].update(batches[0])                    # warm-up on a throw-away copy (allocations, first-launch checks):
+    torch.cuda.synchronize()                         # the measured steps start from the seeded weights themselves
+    model, trainer = fresh()
     held = load() if load is not None else None
-    losses = [trainer.update(b) for b in batches]                        # synchronous steps: each reads its own flags
+    losses, norms, grads = [], [], []
+    for b in batches:                                                    # synchronous steps: each reads its own flags
+        losses.append(trainer.update(b))
+        norms.append(trainer.last_grad_norm)
+        grads.append(model.flat_grad().detach().clone())                 # raw (unclipped) gradient of that step
     torch.cuda.current_stream().synchronize()                            # (not the device: the stand-in is still running)
     still_running = held is not None and not held[1].query()
     torch.cuda.synchronize()
     ops.check_async_errors()
     if held is not None:
         held[1].synchronize()
-    return losses, trainer.last_grad_norm, model._flat_p.detach().clone(), still_running
+    c = model.conv
+    conv_span = model._span(c[0].weight, c[4].bias)
+    return dict(losses=losses, norms=norms, grads=grads, weights=model._flat_p.detach().clone(), conv=conv_span,
+                still_running=still_running)
 
 
 @pytest.mark.parametrize('bsz', [8, 10])
 def test_persistent_steps_beside_a_collective_stand_in(bsz, monkeypatch):
+    """Tolerances.  Step 1 starts from the same seeded weights in both runs, so its loss and everything the recurrence
+    kernels and the side stream's GEMMs produce (the GRU / FC slices of the gradient) are compared tightly.  The conv
+    block's slices are not: its activation is a hard clip, the BatchNorm statistics in front of it are atomic sums whose
+    last bits depend on arrival order, and with ~8 M conv activations per step one of them sits within 1e-7 of the clip
+    boundary in about one seed in four (B = 10, seed 10: element 1621927 of conv2's output normalises to -1.4e-8 ..
+    -7.9e-8) -- whether its gradient passes is then decided by those last bits, in either kernel family and with or
+    without a neighbour (tools/clip_boundary_probe.py).  One such flip moves conv2's filter gradient by 3 % of its
+    largest entry and the NEXT step's loss by 4e-5; the second step is therefore held to 1e-4."""
     from ds2hip import ops
     batches = _batches(bsz, bsz)
     ref = _run('step', batches, monkeypatch, None)
     before = ops.fallback_count
     got = _run('persistent', batches, monkeypatch, lambda: co_resident_load(duration_ms=400.0))
-    assert got[3], 'the stand-in finished before the steps did: it did not share the chip for the whole pass'
+    assert got['still_running'], 'the stand-in finished before the steps did: it did not share the chip for the whole pass'
     assert ops.fallback_count == before and not ops._persistent_off     # nothing fell back to the per-step kernels
-    np.testing.assert_allclose(got[0], ref[0], rtol=2e-5)
-    np.testing.assert_allclose(got[1], ref[1], rtol=2e-4)
-    assert float((got[2] - ref[2]).abs().max()) <= 5e-6
+    np.testing.assert_allclose(got['losses'][0], ref['losses'][0], rtol=2e-6)
+    lo, hi = ref['conv']
+    g, r = got['grads'][0], ref['grads'][0]
+    rest = torch.ones_like(r, dtype=torch.bool)
+    rest[lo:hi] = False
+    assert float((g - r)[rest].abs().max()) <= 2e-5 * float(r[rest].abs().max())      # GRU, BatchNorm1d and FC slices
+    assert float((g - r)[lo:hi].abs().max()) <= 0.05 * float(r[lo:hi].abs().max())    # conv block: admits a clip flip
+    np.testing.assert_allclose(got['norms'][0], ref['norms'][0], rtol=2e-4)
+    np.testing.assert_allclose(got['losses'][1], ref['losses'][1], rtol=1e-4)
+    np.testing.assert_allclose(got['norms'][1], ref['norms'][1], rtol=1e-3)
+    assert float((got['weights'] - ref['weights']).abs().max()) <= 2e-4

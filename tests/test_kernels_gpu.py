@@ -154,6 +154,28 @@ def test_conv_fwd_bwd(ops, monkeypatch, which, bsz, t_in, wlds):
         np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), atol=2e-5)
 
 
+def test_conv2_wgrad_lds_form_repeatable_at_training_size(ops, monkeypatch):
+    """The operands-through-LDS weight-gradient kernel against the direct one at a training shape (B = 10, 6 s: 105 row
+    splits x 58 tap groups, ragged last 64-step chunk), launched 50 times on the same operands: the two differ and the
+    repeats vary only in the last bits of the atomic sums."""
+    torch.manual_seed(3)
+    t1, t = ops.conv_out_frames(601)
+    a1 = torch.randn(10, 32, 61, t1, device=DEV)
+    dy2 = torch.randn(10, 32, 21, t, device=DEV)
+    monkeypatch.setenv('DS2_CONV_WGRAD_LDS', '0')
+    dw_ref, db_ref = torch.empty(32, 32, 21, 11, device=DEV), torch.empty(32, device=DEV)
+    ops.conv_wgrad(2, a1, dy2, t1, dw_ref, db_ref)
+    monkeypatch.setenv('DS2_CONV_WGRAD_LDS', '1')
+    worst_w = worst_b = 0.0
+    for _ in range(50):
+        dw, db = torch.empty_like(dw_ref), torch.empty_like(db_ref)
+        ops.conv_wgrad(2, a1, dy2, t1, dw, db)
+        worst_w = max(worst_w, float((dw - dw_ref).abs().max()))
+        worst_b = max(worst_b, float((db - db_ref).abs().max()))
+    assert worst_w <= 5e-6 * float(dw_ref.abs().max())
+    assert worst_b <= 5e-6 * float(db_ref.abs().max())
+
+
 # ------------------------------------------------------------------------------------------- BN
 @pytest.mark.parametrize('bsz,c,d,t', [(3, 32, 21, 57), (2, 32, 1, 3), (2, 32, 4, 8), (1, 32, 61, 131), (5, 32, 1, 2)])
 def test_bn2d_train_eval_and_backward(ops, bsz, c, d, t):
