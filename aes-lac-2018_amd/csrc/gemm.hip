@@ -13,6 +13,8 @@
 // Numerics: exact fp32 FMA chain in k order per 2-k MFMA (same as fmaf accumulation).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ds2_common.h"
 
 namespace {
@@ -632,6 +634,280 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(int M, int N, int K
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix pipe: error-free operand splitting.
+//
+// Every fp32 operand element is written as a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
+// (round-to-nearest-even at each step; bf16 has fp32's exponent range and 8 significant bits, so the three terms carry all
+// 24 bits of a: |a2| <= 2^-9 |a|, |a3| <= 2^-18 |a|, a - a1 - a2 - a3 = 0 barring underflow).  A product a b is then the sum
+// of nine partial products ai bj, each EXACT in the pipe's fp32 accumulator (8 x 8 significant bits).  NPROD = 9 adds all
+// of them; NPROD = 6 leaves out a2 b3, a3 b2 and a3 b3, together <= 2^-26 |a b| -- a quarter of the rounding error of ONE
+// fp32 product, and far below what the fp32 accumulation of K such products leaves in either kernel family.  The
+// accumulator is fp32 as in the f32-input MFMA kernels above.  v_mfma_f32_32x32x16_bf16 runs 16x the f32-input MFMA's
+// rate, so six of them per 16 k are 2.7x the f32 pipe's peak for the same fp32 result (tests/test_kernels_gpu.py checks
+// both families against an fp64 product; tools/gemm_bench.py times them).
+//
+// Same 128 x 128 tile / 2 x 2 waves / 16-deep slab / double-buffered LDS structure as gemm_tile_body; the split happens
+// once per element on the way from the prefetch registers into LDS (5.5 vector instructions per element), the LDS image
+// is [row][plane][16 k] bf16 (row pitch 112 B: the 16-byte fragment reads of a 32-row tile are conflict-free) and a
+// wave's twelve fragments (2 row tiles + 2 column tiles, 3 planes each) feed 24 MFMAs.
+// ----------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int SP = 112;                         // LDS row pitch, bytes: 3 planes x 16 k x 2 B + 16
+constexpr int SPLIT_TILE_BYTES = 128 * SP;      // one operand slab
+
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+    unsigned int v;                             // round to nearest even, lo -> bits 15:0, hi -> bits 31:16
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v) : "v"(lo), "v"(hi));
+    return v;
+}
+// two fp32 values -> three dwords of packed bf16 pairs (planes 1, 2, 3)
+__device__ __forceinline__ void split3(float a, float b, unsigned int& p1, unsigned int& p2, unsigned int& p3) {
+    p1 = pack_bf16(a, b);
+    float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = pack_bf16(ra, rb);
+    ra -= __builtin_bit_cast(float, p2 << 16);
+    rb -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+    p3 = pack_bf16(ra, rb);
+}
+
+// Prefetch registers of one operand slab: 8 floats per thread.
+//   k-contiguous source: r[4 i + c] = element (x = tid / 4 + 64 i, k = 4 (tid & 3) + c)        (two 16-byte loads)
+//   x-contiguous source: r[c]       = element (x = tid & 127,      k = 8 (tid >> 7) + c)        (eight 4-byte loads, each
+//                                     coalesced over the wave's 64 consecutive x) -- the thread then owns 8 consecutive k
+//                                     of one row, i.e. whole 16-byte runs of the [row][k] image: the transposition costs
+//                                     nothing
+// The per-lane byte offsets are computed ONCE per tile (rows outside the tile get an offset the descriptor's range check
+// rejects: the load returns 0); the slab's advance is wave-uniform and rides in the instruction's scalar offset, so the
+// slab loop holds no vector address arithmetic.  k beyond the operand: an x-contiguous source runs off the end of the
+// descriptor (k * ld + x >= (K - 1) * ld + xmax) and reads 0 by itself; a k-contiguous one would read its next row, so
+// the launcher only selects these kernels for it when K is a multiple of the slab depth.
+template <bool KCONTIG>
+__device__ __forceinline__ void split_voffsets(int ld, int x0, int xmax, int tid, int (&voff)[2]) {
+    if (KCONTIG) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int x = x0 + (tid >> 2) + 64 * i;
+            voff[i] = x < xmax ? (x * ld + (tid & 3) * 4) * 4 : OOB;
+        }
+    } else {
+        const int x = x0 + (tid & 127);
+        voff[0] = voff[1] = x < xmax ? (8 * (tid >> 7) * ld + x) * 4 : OOB;
+    }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void split_load(__amdgpu_buffer_rsrc_t rs, const int (&voff)[2], int ld, int k0, float (&r)[8]) {
+    if (KCONTIG) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], k0 * 4, 0));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[4 * i + c] = v[c];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            r[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[0], (k0 + c) * ld * 4, 0));
+    }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void split_store(char* __restrict__ lds, int tid, const float (&r)[8]) {
+    if (KCONTIG) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned int p[3][2];
+            split3(r[4 * i], r[4 * i + 1], p[0][0], p[1][0], p[2][0]);
+            split3(r[4 * i + 2], r[4 * i + 3], p[0][1], p[1][1], p[2][1]);
+            char* row = lds + ((tid >> 2) + 64 * i) * SP + (tid & 3) * 8;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(row + 32 * q) = make_uint2(p[q][0], p[q][1]);
+        }
+    } else {
+        unsigned int p[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split3(r[2 * c], r[2 * c + 1], p[0][c], p[1][c], p[2][c]);
+        char* row = lds + (tid & 127) * SP + (tid >> 7) * 16;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(row + 32 * q) = make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]);
+    }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, int MODE, int NPROD>
+__device__ __forceinline__ void gemm_split_tile_body(char (&lds)[2][2][SPLIT_TILE_BYTES], int M, int N,
+                                                     const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                     int ldb, float* __restrict__ C, int ldc, float beta, int use_atomic,
+                                                     unsigned int a_bytes, unsigned int b_bytes, int m0, int n0, int kbeg,
+                                                     int kend) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int NI_ = MODE == 0 ? 2 : 1, NJ_ = MODE == 0 ? 2 : MODE;
+    const int arow = MODE == 0 ? wm * 64 : wave * 32, bcol = MODE == 0 ? wn * 64 : 0;
+
+    f32x16 acc[NI_][NJ_];
+#pragma unroll
+    for (int i = 0; i < NI_; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ_; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, b_bytes, 0x00020000);
+    // Two register sets: the loads of slab s + 2 are issued while slab s is multiplied and slab s + 1 (loaded one
+    // iteration earlier) is split into the other LDS buffer -- a 16-deep slab is only 24 MFMAs = 768 pipe cycles per wave,
+    // far less than a global load's latency, so one slab of prefetch distance left every wave parked on vmcnt.
+    float ra[2][8], rb[2][8];
+    int va[2], vb[2];
+    split_voffsets<A_KCONTIG>(lda, m0, M, tid, va);
+    split_voffsets<B_KCONTIG>(ldb, n0, N, tid, vb);
+    const int nslab = (kend - kbeg + BK - 1) / BK;
+    if (nslab > 0) {
+        split_load<A_KCONTIG>(rsa, va, lda, kbeg, ra[0]);
+        split_load<B_KCONTIG>(rsb, vb, ldb, kbeg, rb[0]);
+    }
+    if (nslab > 1) {
+        split_load<A_KCONTIG>(rsa, va, lda, kbeg + BK, ra[1]);
+        split_load<B_KCONTIG>(rsb, vb, ldb, kbeg + BK, rb[1]);
+    }
+    if (nslab > 0) {
+        split_store<A_KCONTIG>(lds[0][0], tid, ra[0]);
+        split_store<B_KCONTIG>(lds[0][1], tid, rb[0]);
+    }
+    __syncthreads();
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int a_off = (arow + lr) * SP + lh * 16, b_off = (bcol + lr) * SP + lh * 16;
+    auto slab = [&](int s, auto PAR) {
+        constexpr int cur = decltype(PAR)::value;                        // s & 1: LDS buffer and register set of slab s
+        // (unconditional: past the last slab the loads fetch zeros or data nobody uses -- under a condition the compiler's
+        // wait-count insertion has to assume they were NOT issued and waits for them together with slab s + 1's)
+        split_load<A_KCONTIG>(rsa, va, lda, kbeg + (s + 2) * BK, ra[cur]);
+        split_load<B_KCONTIG>(rsb, vb, ldb, kbeg + (s + 2) * BK, rb[cur]);
+        const char* as = lds[cur][0] + a_off;
+        const char* bs = lds[cur][1] + b_off;
+        bf16x8 a[NI_][3], b[NJ_][3];
+#pragma unroll
+        for (int i = 0; i < NI_; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(as + i * 32 * SP + q * 32);
+#pragma unroll
+        for (int j = 0; j < NJ_; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * SP + q * 32);
+#pragma unroll
+        for (int i = 0; i < NI_; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ_; ++j) {
+                f32x16 c = acc[i][j];
+                if (NPROD == 9) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][1], c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        // (unconditional as well: behind the last slab it fills a buffer nobody reads)
+        split_store<A_KCONTIG>(lds[cur ^ 1][0], tid, ra[cur ^ 1]);
+        split_store<B_KCONTIG>(lds[cur ^ 1][1], tid, rb[cur ^ 1]);
+        // issue order: the compiler puts the 88 vector instructions of the split behind the last MFMA; spread them (and the
+        // LDS stores) between the MFMAs, whose issue takes 8 of their 32 pipe cycles
+        constexpr int NMFMA = NI_ * NJ_ * NPROD, VPM = (96 + NMFMA - 1) / NMFMA, WEVERY = NMFMA >= 8 ? NMFMA / 8 : 1;
+        __builtin_amdgcn_sched_group_barrier(0x020, (A_KCONTIG ? 2 : 8) + (B_KCONTIG ? 2 : 8), 0);     // slab s + 2's loads first
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * (NI_ + NJ_), 0);
+#pragma unroll
+        for (int g = 0; g < NMFMA; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            if (g % WEVERY == WEVERY - 1) __builtin_amdgcn_sched_group_barrier(0x200, NMFMA >= 8 ? 1 : 8 / NMFMA + 1, 0);
+        }
+        __syncthreads();
+    };
+    for (int s = 0; s < nslab; s += 2) {
+        slab(s, std::integral_constant<int, 0>{});
+        if (s + 1 < nslab) slab(s + 1, std::integral_constant<int, 1>{});
+    }
+
+#pragma unroll
+    for (int i = 0; i < NI_; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ_; ++j) {
+            const int n = n0 + bcol + j * 32 + lr;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + arow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) {
+                    float* c = C + (size_t)m * ldc + n;
+                    if (use_atomic)
+                        atomicAdd(c, acc[i][j][r]);
+                    else
+                        *c = (beta != 0.f) ? acc[i][j][r] + beta * (*c) : acc[i][j][r];
+                }
+            }
+        }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, int NPROD>
+__device__ __forceinline__ void gemm_split_tile(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                                float beta, int tiles_n, int k_per_split, int use_atomic,
+                                                unsigned int a_bytes, unsigned int b_bytes, int tile, int split) {
+    __shared__ __attribute__((aligned(16))) char lds[2][2][SPLIT_TILE_BYTES];  // [buf][A|B]
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int ncols = N - n0;                                            // wave-uniform (scalar) choice
+    if (ncols <= 32)
+        gemm_split_tile_body<A_KCONTIG, B_KCONTIG, 1, NPROD>(lds, M, N, A, lda, B, ldb, C, ldc, beta, use_atomic, a_bytes,
+                                                             b_bytes, m0, n0, kbeg, kend);
+    else if (ncols <= 64)
+        gemm_split_tile_body<A_KCONTIG, B_KCONTIG, 2, NPROD>(lds, M, N, A, lda, B, ldb, C, ldc, beta, use_atomic, a_bytes,
+                                                             b_bytes, m0, n0, kbeg, kend);
+    else
+        gemm_split_tile_body<A_KCONTIG, B_KCONTIG, 0, NPROD>(lds, M, N, A, lda, B, ldb, C, ldc, beta, use_atomic, a_bytes,
+                                                             b_bytes, m0, n0, kbeg, kend);
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                            const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                            int ldc, float beta, int tiles_n, int k_per_split,
+                                                            int use_atomic, unsigned int a_bytes, unsigned int b_bytes) {
+    gemm_split_tile<A_KCONTIG, B_KCONTIG, NPROD>(M, N, K, A, lda, B, ldb, C, ldc, beta, tiles_n, k_per_split, use_atomic,
+                                                 a_bytes, b_bytes, xcd_tile(blockIdx.x, gridDim.x), blockIdx.y);
+}
+template <int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x_tn_group_kernel(GemmGroup g, int N, int K, int tiles_n, int k_per_split) {
+    const int p = blockIdx.z;
+    const int tiles = ((g.M[p] + BM - 1) / BM) * tiles_n;
+    if ((int)blockIdx.x >= tiles) return;
+    gemm_split_tile<false, false, NPROD>(g.M[p], N, K, g.A[p], g.lda[p], g.B[p], g.ldb[p], g.C[p], g.ldc[p], 0.f, tiles_n,
+                                         k_per_split, 1, g.a_bytes[p], g.b_bytes[p], blockIdx.x, blockIdx.y);
+}
+
+// Kernel family: 0 = f32-input MFMA kernels only, 6 (default) / 9 = the split-operand kernels with that many partial
+// products.  DS2_GEMM_SPLIT sets the process default; ds2_gemm_split_mode() changes it at run time (the tests compare the
+// families in one process).
+inline int& gemm_split_mode_ref() {
+    static int mode = [] {
+        const char* e = getenv("DS2_GEMM_SPLIT");
+        const int v = e ? atoi(e) : 6;
+        return (v == 6 || v == 9) ? v : 0;
+    }();
+    return mode;
+}
+inline int gemm_split_mode() { return gemm_split_mode_ref(); }
+
 // zero `rows` rows of N floats with leading dimension ldc: ONE linear fill when the rows are contiguous (the 2-D fill of the
 // runtime runs at ~0.4 TB/s: 38 us for the 16 MB of a dX output against ~8 us for the linear one)
 inline void zero_rows(float* C, int ldc, int N, int rows, hipStream_t st) {
@@ -675,6 +951,25 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
         }
     }
     if (split_k < 1) split_k = 1;
+    if (gemm_split_mode() != 0 && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
+        ((!AK && !BKc) || K % BK == 0)) {
+        int kper = ds2_cdiv(ds2_cdiv(K, split_k), BK) * BK;
+        if (kper < BK) kper = BK;
+        const int nsplit = ds2_cdiv(K, kper);
+        const unsigned long long abytes = 4ull * (AK ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
+        const unsigned long long bbytes = 4ull * (BKc ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
+        if (abytes >= 0x7FFFFFF0ull || bbytes >= 0x7FFFFFF0ull) return -1;
+        dim3 grid(tm * tn, nsplit), block(256);
+        const int atomic = nsplit > 1 ? 1 : 0;
+        if (atomic && beta == 0.f) zero_rows(C, ldc, N, M, st);
+        if (gemm_split_mode() == 6)
+            hipLaunchKernelGGL((gemm_bf16x_kernel<AK, BKc, 6>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc, beta, tn,
+                               kper, atomic, (unsigned int)abytes, (unsigned int)bbytes);
+        else
+            hipLaunchKernelGGL((gemm_bf16x_kernel<AK, BKc, 9>), grid, block, 0, st, M, N, K, A, lda, B, ldb, C, ldc, beta, tn,
+                               kper, atomic, (unsigned int)abytes, (unsigned int)bbytes);
+        return 0;
+    }
     const bool vec0 = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
                       ((!AK && !BKc) || K % 4 == 0);
     static const bool v2_on = !(getenv("DS2_GEMM_V2") && getenv("DS2_GEMM_V2")[0] == '0');    // A/B timing switch
@@ -793,6 +1088,11 @@ extern "C" int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const
     return DS2_OK;
 }
 
+extern "C" int ds2_gemm_split_mode(int mode) {
+    if (mode == 0 || mode == 6 || mode == 9) gemm_split_mode_ref() = mode;
+    return gemm_split_mode();
+}
+
 extern "C" int ds2_gemm_f32_tn_group(int count, const float* const* A_host, const int* lda_host, const int* M_host,
                                      const float* const* B_host, const int* ldb_host, float* const* C_host,
                                      const int* ldc_host, int N, int K, int accumulate, void* stream) {
@@ -845,7 +1145,11 @@ extern "C" int ds2_gemm_f32_tn_group(int count, const float* const* A_host, cons
     for (int p = 0; p < count && !accumulate; ++p)               // partial products are accumulated with atomics
         zero_rows(g.C[p], g.ldc[p], N, g.M[p], st);
     dim3 grid(max_tiles, nsplit, count), block(256);
-    if (vec)
+    if (vec && gemm_split_mode() == 6)
+        hipLaunchKernelGGL((gemm_bf16x_tn_group_kernel<6>), grid, block, 0, st, g, N, K, tn, kper);
+    else if (vec && gemm_split_mode() == 9)
+        hipLaunchKernelGGL((gemm_bf16x_tn_group_kernel<9>), grid, block, 0, st, g, N, K, tn, kper);
+    else if (vec)
         hipLaunchKernelGGL((gemm_f32_tn_group_kernel<true>), grid, block, 0, st, g, N, K, tn, kper);
     else
         hipLaunchKernelGGL((gemm_f32_tn_group_kernel<false>), grid, block, 0, st, g, N, K, tn, kper);

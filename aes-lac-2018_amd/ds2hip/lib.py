@@ -26,6 +26,7 @@ SIGNATURES = {
     'ds2_pcm16_to_float': (_I, [_P, _Z, _F, _P, _P]),
     'ds2_wsola_tempo': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'ds2_gain_requantize': (_I, [_P, _P, _P, _I, _F, _P, _P]),
+    'ds2_gemm_split_mode': (_I, [_I]),
     'ds2_gemm_f32': (_I, [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _F, _I, _P]),
     'ds2_gemm_f32_tn_group': (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ds2_transpose_btf_to_bft': (_I, [_P, _I, _I, _I, _P, _P]),

@@ -216,6 +216,12 @@ def gemm(a, b, trans_a=False, trans_b=False, out=None, beta=0.0, m=None, n=None,
     return out
 
 
+def gemm_split_mode(mode=-1):
+    """Select the GEMM kernel family (0: f32-input MFMA, 6 / 9: bf16 split-operand kernels, include/ds2hip.h); returns the
+    one in effect.  -1 only queries."""
+    return int(lib.load().ds2_gemm_split_mode(int(mode)))
+
+
 def gemm_raw(trans_a, trans_b, m, n, k, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, beta=0.0, split_k=1):
     """Pointer-level GEMM for sub-matrix views (pointers are ints = data_ptr() + byte offsets)."""
     lib.call('ds2_gemm_f32', int(trans_a), int(trans_b), m, n, k, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, float(beta),

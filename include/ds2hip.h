@@ -85,7 +85,22 @@ int ds2_gain_requantize(const float* x, const int64_t* offsets, const float* gai
  * partial products with float atomics (C is zero-filled first when beta = 0; the last bits then
  * depend on arrival order); split_k = 0 picks a split that fills the chip when M*N alone gives
  * fewer than ~384 tiles (the dW = dG^T X products: small M*N, K = T*B).
+ *
+ * Arithmetic.  Operands, accumulator and result are fp32.  Two kernel families compute the products:
+ *   mode 0      the f32-input matrix instruction (v_mfma_f32_32x32x2_f32): an fp32 FMA chain;
+ *   mode 6 / 9  every fp32 operand element is split without error into three bf16 terms a = a1 + a2 + a3
+ *               (round-to-nearest at each step: the three 8-bit significands carry all 24 bits), and a * b is summed from
+ *               partial products ai * bj on the bf16 matrix instruction, each exact in its fp32 accumulator.  Mode 9 adds
+ *               all nine; mode 6 (the default) leaves out a2 b3 + a3 b2 + a3 b3 <= 2^-26 |a b|, a quarter of one fp32
+ *               rounding.  Measured against fp64 the three agree to the last digit shown (tools/gemm_split_check.py:
+ *               max error / sum|a||b| 2.9e-7 at K = 672 in modes 6 and 9, 3.2e-7 in mode 0).  Not handled like mode 0:
+ *               an operand element beyond bf16's largest finite value (3.39e38) or an infinity gives NaN, and terms below
+ *               2^-126 are flushed (operands below ~2^-108 lose low bits).
+ * ds2_gemm_split_mode(mode) selects the family for later calls (0, 6 or 9; anything else only queries) and returns the one
+ * in effect; the process default is DS2_GEMM_SPLIT or 6.  Mode 6 / 9 needs 16-byte aligned operands with leading dimensions
+ * that are multiples of 4 and, for an operand stored with K contiguous, K % 16 == 0; other calls use mode 0's kernels.
  */
+int ds2_gemm_split_mode(int mode);
 int ds2_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B,
                  int ldb, float* C, int ldc, float beta, int split_k, void* stream);
 /* Up to four TN problems C_p[M_p, N] = A_p^T B_p that share N and K in ONE launch (A_p stored K x M_p with leading

@@ -22,12 +22,22 @@ def _t(a):
 
 
 # ------------------------------------------------------------------------------------------- GEMM
+@pytest.fixture
+def gemm_family(ops, request):
+    """Kernel family of ds2_gemm_f32 for one test (0: f32-input MFMA, 6 / 9: bf16 split-operand kernels)."""
+    before = ops.gemm_split_mode()
+    assert ops.gemm_split_mode(request.param) == request.param
+    yield request.param
+    ops.gemm_split_mode(before)
+
+
+@pytest.mark.parametrize('gemm_family', [0, 6], indirect=True)
 @pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize('m,n,k', [(128, 128, 16), (300, 200, 100), (37, 29, 800), (1000, 4800, 672),
                                    (29, 800, 555), (5, 7, 3), (257, 129, 33),
                                    (4240, 4800, 800), (3001, 2999, 301), (2100, 4000, 17), (8200, 4100, 40),
                                    (1330, 800, 4800), (260, 192, 2100)])     # edge tiles of 32 / 64 columns + split-K
-def test_gemm_matches_fp64(ops, ta, tb, m, n, k):
+def test_gemm_matches_fp64(ops, gemm_family, ta, tb, m, n, k):
     rng = np.random.default_rng(m * 7 + n * 3 + k + ta * 2 + tb)
     a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
     b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
@@ -35,6 +45,56 @@ def test_gemm_matches_fp64(ops, ta, tb, m, n, k):
     out = ops.gemm(_t(a), _t(b), trans_a=bool(ta), trans_b=bool(tb)).cpu().numpy()
     # fp32 accumulation noise: rounding of partial sums whose magnitude grows like sqrt(k), over k terms (outputs ~ sqrt(k))
     np.testing.assert_allclose(out, ref, rtol=0, atol=max(8e-6 * np.sqrt(k), 4e-7 * k))
+
+
+@pytest.mark.parametrize('ta,tb,m,n,k,split_k', [(0, 1, 1000, 800, 672, 1), (0, 0, 1111, 800, 4800, 1), (1, 0, 4800, 800, 3001, 1),
+                                                 (1, 0, 1600, 800, 4240, 0), (1, 1, 384, 256, 512, 1), (0, 1, 512, 512, 2048, 1)])
+def test_gemm_split_operand_kernels_are_as_accurate_as_the_f32_kernels(ops, ta, tb, m, n, k, split_k):
+    """ds2_gemm_f32's default kernels multiply on the bf16 matrix pipe after an error-free three-way split of every fp32
+    operand (include/ds2hip.h).  Error against an fp64 product, relative to sum_k |a||b| (the scale fp32 rounding errors
+    are proportional to), for the f32-input kernels (mode 0), the six-product kernels (6, the default) and the
+    nine-product kernels (9): the split kernels must be no worse than mode 0 -- on operands of order one and on operands
+    whose magnitudes spread over e^(+-24) (the last shape), where a dropped low-order product would show."""
+    torch.manual_seed(m + k)
+    a = torch.randn((k, m) if ta else (m, k), device=DEV)
+    b = torch.randn((n, k) if tb else (k, n), device=DEV)
+    if k == 2048:
+        a = a * torch.exp(8 * torch.randn_like(a))
+        b = b * torch.exp(8 * torch.randn_like(b))
+    a64, b64 = (a.t() if ta else a).double(), (b.t() if tb else b).double()
+    ref, scale = a64 @ b64, a64.abs() @ b64.abs()
+    before = ops.gemm_split_mode()
+    err = {}
+    try:
+        for mode in (0, 6, 9):
+            ops.gemm_split_mode(mode)
+            c = ops.gemm(a, b, trans_a=bool(ta), trans_b=bool(tb), split_k=split_k)
+            e = (c.double() - ref).abs() / scale
+            err[mode] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    finally:
+        ops.gemm_split_mode(before)
+    for mode in (6, 9):
+        assert err[mode][0] <= 1.25 * err[0][0] + 1e-8, err            # max
+        assert err[mode][1] <= 1.25 * err[0][1] + 1e-9, err            # rms
+    assert err[6][0] <= 3e-6 and err[0][0] <= 3e-6, err               # and all of them are fp32-grade in absolute terms
+
+
+@pytest.mark.parametrize('gemm_family', [0, 6, 9], indirect=True)
+def test_gemm_exact_on_small_integers(ops, gemm_family):
+    """Integer operands whose products and sums fit 24 bits: every family must return the exact result (the split terms
+    carry all 24 bits of an operand, the partial products are exact)."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(-2047, 2048, size=(256, 64)).astype(np.float32)
+    b = rng.integers(-63, 64, size=(192, 64)).astype(np.float32)
+    out = ops.gemm(_t(a), _t(b), trans_b=True).cpu().numpy()
+    assert np.array_equal(out, a.astype(np.int64) @ b.astype(np.int64).T)
+    a[3, 5] = 16777215.0                                               # all 24 bits set: needs all three terms
+    b[:, 5] = 0.0
+    b[7, 5] = 1.0
+    a[3, :5] = 0.0
+    a[3, 6:] = 0.0
+    out = ops.gemm(_t(a), _t(b), trans_b=True).cpu().numpy()
+    assert out[3, 7] == 16777215.0
 
 
 def test_gemm_beta_and_splitk(ops):
