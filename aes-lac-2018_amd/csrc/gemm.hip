@@ -944,7 +944,11 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
         const int tiles = tm * tn;
         split_k = 1;
         if ((tiles < 512 && K >= 512) || (tiles < 2048 && K >= 2048)) {
-            split_k = 8192 / tiles;
+            // (the split-operand kernels run a work item ~1.6x faster, so prologue, epilogue and atomics weigh more: stand-alone
+            // dX 242 -> 213 us and dW_ih 242 -> 226 us with ~1024 items instead of ~8192, whole step -0.9 %)
+            static const int env_target = getenv("DS2_GEMM_SPLIT_TARGET") ? atoi(getenv("DS2_GEMM_SPLIT_TARGET")) : 0;
+            const int target = env_target > 0 ? env_target : (gemm_split_mode() != 0 ? 1024 : 8192);
+            split_k = target / tiles;
             const int max_split = K / 320 > 1 ? K / 320 : 1;
             if (split_k > max_split) split_k = max_split;
             if (split_k > 32) split_k = 32;
@@ -959,6 +963,9 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
         const unsigned long long abytes = 4ull * (AK ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
         const unsigned long long bbytes = 4ull * (BKc ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
         if (abytes >= 0x7FFFFFF0ull || bbytes >= 0x7FFFFFF0ull) return -1;
+        // (stream-K runs for a partial last round of tiles, as gemm_f32_v2_kernel has them, were built and measured: gi at
+        // B = 10, 1292 tiles on 512 slots, 209 -> 204 us, 4096 x 4736 x 800 180 -> 189 us -- these kernels run against the
+        // chip's power limit, idle slots give their share back as clock; not kept)
         dim3 grid(tm * tn, nsplit), block(256);
         const int atomic = nsplit > 1 ? 1 : 0;
         if (atomic && beta == 0.f) zero_rows(C, ldc, N, M, st);
@@ -1132,7 +1139,9 @@ extern "C" int ds2_gemm_f32_tn_group(int count, const float* const* A_host, cons
     // split K so that the launch has ~3 work items per resident slot (the rule of the single launch), >= 320 k per item
     int split_k = 1;
     if (tot_tiles < 512 && K >= 512) {
-        split_k = 3072 / tot_tiles;
+        static const int env_target = getenv("DS2_GEMM_GROUP_TARGET") ? atoi(getenv("DS2_GEMM_GROUP_TARGET")) : 0;
+        const int target = env_target > 0 ? env_target : (gemm_split_mode() != 0 ? 1024 : 3072);
+        split_k = target / tot_tiles;
         const int max_split = K / 320 > 1 ? K / 320 : 1;
         if (split_k > max_split) split_k = max_split;
         if (split_k > 32) split_k = 32;
