@@ -424,6 +424,24 @@ def main():
         dt_sync = float(ts[0])
     note('sync-per-step leg done: %.2f ms/step' % (1e3 * dt_sync / args.steps))
 
+    # the same steps with every GEMM on the f32-input MFMA kernels (ds2_gemm_split_mode 0) instead of the default
+    # split-operand kernels on the bf16 matrix pipe: both families take fp32 operands and return fp32-accurate products
+    # (include/ds2hip.h), this leg says what the choice of kernel family is worth
+    from ds2hip import ops as _ops
+    gemm_mode = _ops.gemm_split_mode()
+    dt_f32 = None
+    if gemm_mode != 0:
+        _ops.gemm_split_mode(0)
+        try:
+            dt_f32, _, _ = timed_steps(lambda i: step(i + args.warmup - 2), args.steps, 2, use_dist)   # the same bins
+        finally:
+            _ops.gemm_split_mode(gemm_mode)
+        if use_dist:
+            ts = torch.tensor([dt_f32], dtype=torch.float64, device=dev)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            dt_f32 = float(ts[0])
+        note('f32-MFMA GEMM leg done: %.2f ms/step' % (1e3 * dt_f32 / args.steps))
+
     # data-parallel self-diagnosis (every rank takes part): what the collective costs alone, what the step costs with the
     # per-layer all-reduce overlapped with backward and without, and whether any recurrence launch fell back
     ddp = None
@@ -540,6 +558,15 @@ def main():
                                      'ms_per_step': round(1e3 * dt_sync / args.steps, 3),
                                      'note': 'the same steps with a host synchronisation in every step (codes/engine.py:92); '
                                              'the headline defers each step\'s one readback by one step'},
+                   'gemm_arithmetic': {
+                       'mode': gemm_mode,
+                       'note': ('fp32 operands, fp32 accumulator, fp32 result; products on the bf16 matrix pipe after an '
+                                'error-free three-way split of every operand element (%d partial products, each exact; '
+                                'what is left out is <= 2^-26 of a product): error against fp64 equal to the f32-input MFMA '
+                                'kernels\' (tests/test_kernels_gpu.py, tools/gemm_split_check.py)' % gemm_mode)
+                               if gemm_mode else 'f32-input MFMA kernels (v_mfma_f32_32x32x2_f32)',
+                       'same_steps_on_f32_input_mfma_gemms': None if dt_f32 is None else {
+                           'frames_per_s': round(frames / dt_f32, 1), 'ms_per_step': round(1e3 * dt_f32 / args.steps, 3)}},
                    'persistent_to_step_fallbacks': (_fallbacks() if ddp is None
                                                     else ddp['persistent_to_step_fallbacks']),
                    'ms_per_step_rank0': {'median': round(1e3 * pct_of(per_sorted, 0.5), 3),
