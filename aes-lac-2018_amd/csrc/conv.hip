@@ -586,8 +586,10 @@ inline int conv_tout(int which, int tin) { return which == 1 ? (tin + 20 - 11) /
 
 extern "C" size_t ds2_conv_wt_ws_floats(int which) {
     const ConvGeom g = geom(which);
-    return (size_t)32 * g.kf * KTP * 32 > (size_t)g.cin * g.kf * KTP * 32 ? (size_t)32 * g.kf * KTP * 32
-                                                                          : (size_t)g.cin * g.kf * KTP * 32;
+    const size_t direct = (size_t)32 * g.kf * KTP * 32 > (size_t)g.cin * g.kf * KTP * 32 ? (size_t)32 * g.kf * KTP * 32
+                                                                                       : (size_t)g.cin * g.kf * KTP * 32;
+    const size_t split = which == 2 ? ds2_conv2_split_ws_floats() : 0;           // conv_split.hip's tables and filter image
+    return direct > split ? direct : split;
 }
 
 extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, const float* bias, int B,
@@ -598,6 +600,10 @@ extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, con
     const int tin = t_in_frames, tout = conv_tout(which, tin);
     DS2_CHECK_ARG(tout > 0);
     hipStream_t st = (hipStream_t)stream;
+    if (which == 2 && ds2_conv2_fwd_split(in, weight, bias, B, tin, out, wt_ws, st) == 0) {   // gather-GEMM, conv_split.hip
+        DS2_CHECK_LAUNCH();
+        return DS2_OK;
+    }
     const int total = g.cin * g.kf * KTP * 32;
     hipLaunchKernelGGL(conv_wt_layout_kernel, dim3(ds2_cdiv(total, 256)), dim3(256), 0, st, weight, g.cin, g.kf, g.kt,
                        0, wt_ws);
@@ -661,10 +667,19 @@ extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, con
     return DS2_OK;
 }
 
+extern "C" size_t ds2_conv2_dgrad_ws_floats(int B, int T1) {
+    const size_t direct = ds2_conv_wt_ws_floats(2), split = ds2_conv2_dgrad_split_ws_floats(B, T1);
+    return direct > split ? direct : split;
+}
+
 extern "C" int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, int T1, float* d_in, float* wt_ws,
                                void* stream) {
     DS2_CHECK_ARG(d_out && weight && d_in && wt_ws && B > 0 && T1 > 10);
     hipStream_t st = (hipStream_t)stream;
+    if (ds2_conv2_dgrad_split(d_out, weight, B, T1, d_in, wt_ws, st) == 0) {      // gather-GEMM, conv_split.hip
+        DS2_CHECK_LAUNCH();
+        return DS2_OK;
+    }
     const int T = T1 - 10;
     const int total = 32 * 21 * KTP * 32;
     hipLaunchKernelGGL(conv_wt_layout_kernel, dim3(ds2_cdiv(total, 256)), dim3(256), 0, st, weight, 32, 21, 11, 1,

@@ -1,0 +1,61 @@
+// fp32 products on the bf16 matrix pipe: error-free three-way operand splitting (shared by gemm.hip and conv_split.hip).
+//
+// a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2), round-to-nearest-even at each step: bf16 has
+// fp32's exponent range and 8 significant bits, so the three terms carry all 24 bits of a (|a2| <= 2^-9 |a|,
+// |a3| <= 2^-18 |a|).  A product a b is the sum of nine partial products ai bj, each EXACT in the matrix instruction's fp32
+// accumulator; the kernels add six of them (a2 b3 + a3 b2 + a3 b3 <= 2^-26 |a b| is left out) or all nine.
+#pragma once
+#include "ds2_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// LDS image of an operand slab: [row][plane][16 k] bf16, row pitch 112 B = 3 planes x 32 B + 16: the 16-byte fragment reads of
+// a 32-row MFMA operand (row = lane & 31, k half = lane >> 5) are conflict-free for ds_read_b128's four 16-lane groups.
+constexpr int SPLIT_PITCH = 112;
+
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+    unsigned int v;                             // round to nearest even, lo -> bits 15:0, hi -> bits 31:16
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v) : "v"(lo), "v"(hi));
+    return v;
+}
+// two fp32 values -> three dwords of packed bf16 pairs (planes 1, 2, 3)
+__device__ __forceinline__ void split3(float a, float b, unsigned int& p1, unsigned int& p2, unsigned int& p3) {
+    p1 = pack_bf16(a, b);
+    float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = pack_bf16(ra, rb);
+    ra -= __builtin_bit_cast(float, p2 << 16);
+    rb -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+    p3 = pack_bf16(ra, rb);
+}
+// eight consecutive k of one row -> the row's three 16-byte runs
+__device__ __forceinline__ void split_store_row8(char* __restrict__ row, const float (&r)[8]) {
+    unsigned int p[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) split3(r[2 * c], r[2 * c + 1], p[0][c], p[1][c], p[2][c]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(row + 32 * q) = make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]);
+}
+// four consecutive k of one row -> 8 bytes in each of the row's three planes
+__device__ __forceinline__ void split_store_row4(char* __restrict__ row, float r0, float r1, float r2, float r3) {
+    unsigned int p[3][2];
+    split3(r0, r1, p[0][0], p[1][0], p[2][0]);
+    split3(r2, r3, p[0][1], p[1][1], p[2][1]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(row + 32 * q) = make_uint2(p[q][0], p[q][1]);
+}
+// the six (or nine) partial products of one 32 x 32 x 16 step
+template <int NPROD>
+__device__ __forceinline__ f32x16 split_mfma(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+    if (NPROD == 9) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[1], c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+}

@@ -32,6 +32,7 @@ SIGNATURES = {
     'ds2_transpose_btf_to_bft': (_I, [_P, _I, _I, _I, _P, _P]),
     'ds2_conv_wt_ws_floats': (_Z, [_I]),
     'ds2_conv_fwd': (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    'ds2_conv2_dgrad_ws_floats': (_Z, [_I, _I]),
     'ds2_conv2_dgrad': (_I, [_P, _P, _I, _I, _P, _P, _P]),
     'ds2_conv_wgrad': (_I, [_I, _P, _P, _I, _I, _P, _P, _P]),
     'ds2_bn_ws_bytes': (_Z, [_I]),

@@ -119,13 +119,18 @@ int ds2_gemm_f32_tn_group(int count, const float* const* A_host, const int* lda_
  *          kernel (32,1,41,11), stride (2,2), padding (0,10)
  *   conv2: a1 (B,32,61,T1) -> y (B,32,21,T); kernel (32,32,21,11), stride (2,1), no padding
  * which = 1 or 2.  Weights are passed in the torch layout (Cout,Cin,KF,KT) plus bias (32).
- * wt_ws: workspace of ds2_conv_wt_ws_floats(which) floats for the re-laid-out filter.
+ * wt_ws: workspace of ds2_conv_wt_ws_floats(which) floats for the re-laid-out filter (ds2_conv2_dgrad: of
+ * ds2_conv2_dgrad_ws_floats(B, T1) floats -- its default form also keeps a zero-bordered copy of d_out there).
+ * Arithmetic of conv2's forward pass and data gradient: fp32 operands, accumulator and result; by default the products run
+ * on the bf16 matrix pipe after the error-free three-way operand split described at ds2_gemm_f32 (six exact partial
+ * products; DS2_CONV_SPLIT=9 all nine, =0 the direct kernels on the f32-input matrix instruction).
  */
 int ds2_transpose_btf_to_bft(const float* x, int B, int T, int F, float* x_t, void* stream);
 size_t ds2_conv_wt_ws_floats(int which);
 int ds2_conv_fwd(int which, const float* in, const float* weight, const float* bias, int B, int t_in_frames,
                  float* out, float* wt_ws, void* stream);
 /* dgrad (conv2 only): d_in (B,32,61,T1) from d_out (B,32,21,T) */
+size_t ds2_conv2_dgrad_ws_floats(int B, int T1);
 int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, int T1, float* d_in, float* wt_ws,
                     void* stream);
 /* wgrad: d_weight (Cout,Cin,KF,KT) and d_bias (32) OVERWRITTEN (d_weight zeroed inside) */
