@@ -43,7 +43,7 @@ struct GatherGeom {
     int o_base, o_b_stride, o_row_stride, o_col_stride;
 };
 
-template <int NPROD>
+template <int NPROD, int NT>
 __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __restrict__ A, unsigned int a_bytes,
                                                               const int* __restrict__ tap_off,
                                                               const unsigned int* __restrict__ Wp, unsigned int w_bytes,
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
     // L2 then holds the 21 input rows its neighbouring tiles share)
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, qd = nwg >> 3, rm = nwg & 7;
     const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
-    const int m0 = tile * 256;
+    constexpr int WG_M = 128 * NT;                                       // positions per workgroup: 4 waves x NT row tiles of 32
+    const int m0 = tile * WG_M;
     const int nstep_all = g.npairs * g.ngroups;
     const int sbeg = blockIdx.y * steps_per_split, send = min(nstep_all, sbeg + steps_per_split);
     auto decode = [&](int p, int& va, int& vo) {
@@ -69,22 +70,22 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
             vo = g.o_base + b * g.o_b_stride + r * g.o_row_stride + t;
         }
     };
-    int va[2], vo_unused;
-    {
+    int va[NT], vo_unused;
+    if (tid < WG_M) {
         int a_, o_;
         decode(m0 + tid, a_, o_);
         sh_o[tid] = o_;
     }
-    decode(m0 + wave * 64 + lr, va[0], vo_unused);
-    decode(m0 + wave * 64 + 32 + lr, va[1], vo_unused);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) decode(m0 + wave * 32 * NT + 32 * i + lr, va[i], vo_unused);
     __syncthreads();
     const int vw = (lr * 16 + lh * 8) * 2;                               // filter fragment: [step][plane][oc][k half][8] bf16
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(Wp), 0, w_bytes, 0x00020000);
 
-    f32x16 acc[2];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
     // the Infinity Cache, and with one set in flight the waves spent half their cycles waiting for them.)
     constexpr int NSET = 4;
     int cp = sbeg / g.ngroups, gq = sbeg - cp * g.ngroups;               // (channel pair, tap group) of the next table read
-    f32x4 ra[NSET][2][2];                                                // [set][row tile][run of 4 taps]
+    f32x4 ra[NSET][NT][2];                                               // [set][row tile][run of 4 taps]
     uint4 rw[NSET][3];
     int so[2];
     auto read_tab = [&](int (&o)[2]) {
@@ -107,9 +108,9 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
             ++cp;
         }
     };
-    auto issue = [&](int s, f32x4 (&a)[2][2], uint4 (&w)[3], const int (&o)[2]) {
+    auto issue = [&](int s, f32x4 (&a)[NT][2], uint4 (&w)[3], const int (&o)[2]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
                 a[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, va[i], o[h], 0));
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
         constexpr int nxt = (cur + NSET - 1) % NSET;
         issue(s + NSET - 1, ra[nxt], rw[nxt], so);                       // (past the end: zeros or values nobody uses; the
         read_tab(so);                                                    // table and the filter image are padded)
-        bf16x8 a[2][3], b[3];
+        bf16x8 a[NT][3], b[3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NT; ++i) {
             unsigned int p[3][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) b[q] = __builtin_bit_cast(bf16x8, rw[cur][q]);
-        acc[0] = split_mfma<NPROD>(a[0], b, acc[0]);
-        acc[1] = split_mfma<NPROD>(a[1], b, acc[1]);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = split_mfma<NPROD>(a[i], b, acc[i]);
     };
     for (int s = sbeg; s < send; s += NSET) {
         step(s, std::integral_constant<int, 0>{});
@@ -155,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
     const float bv = (bias != nullptr && blockIdx.y == 0) ? bias[lr] : 0.f;
     const int ocol = lr * g.o_col_stride;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = wave * 32 * NT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int ob = sh_o[m];
             if (ob >= 0) {
                 float* c = out + (size_t)ob + ocol;
@@ -254,13 +255,34 @@ int conv_split_mode() {
     return (v == 6 || v == 9) ? v : 0;
 }
 
-// K splits: one wave owns 64 positions, so a short minibatch has fewer waves than the chip has SIMDs (1024) -- split K
-// (float atomics into a zeroed output) until there are about that many.  Measured, B = 10, forward, ms, 1 / 2 splits:
-// T_in = 200 0.211 / 0.155, 300 0.217 / 0.187, 500 0.232 / 0.252, 830 0.343 / 0.391, 1501 0.559 / 0.633.
-int pick_ksplit(int tiles) {
-    static const int force = getenv("DS2_CONV_SPLIT_KS") ? atoi(getenv("DS2_CONV_SPLIT_KS")) : 0;
-    if (force > 0) return force;
-    return tiles >= 180 ? 1 : (tiles >= 100 ? 2 : 3);
+// Work decomposition.  A wave owns 64 positions (two row tiles sharing the filter fragments) when that still gives every
+// SIMD about two waves, else 32; when even those are fewer than the chip's 1024 SIMDs (a short minibatch), K is split over
+// workgroups too (float atomics into a zeroed output).  Measured, B = 10, forward, ms (64 positions: 1 / 2 splits):
+// T_in = 200 0.211 / 0.155, 300 0.217 / 0.187, 500 0.232 / 0.252, 830 0.343 / 0.391, 1501 0.559 / 0.633 -- at 830 the
+// 1332 waves leave a SIMD with one or two of them and the kernel takes the time of two.
+void launch_gather(int mode, const float* A, unsigned int a_bytes, const int* tab, const unsigned int* Wp, unsigned int w_bytes,
+                   const float* bias, float* out, unsigned long long o_elems, const GatherGeom& g, int nstep, bool* zeroed,
+                   hipStream_t st) {
+    static const int force_ks = getenv("DS2_CONV_SPLIT_KS") ? atoi(getenv("DS2_CONV_SPLIT_KS")) : 0;
+    static const int force_nt = getenv("DS2_CONV_SPLIT_NT") ? atoi(getenv("DS2_CONV_SPLIT_NT")) : 0;
+    const int waves64 = ds2_cdiv(g.M, 64);
+    const int nt = force_nt > 0 ? force_nt : (waves64 >= 1536 ? 2 : 1);   // (B = 10: T_in 500 0.217 / 0.252 ms with 32 / 64, 830 a tie, 1100 0.469 / 0.403)
+    const int tiles = ds2_cdiv(g.M, 128 * nt), waves = tiles * 4;
+    const int ks = force_ks > 0 ? force_ks : (waves >= 1024 ? 1 : (waves >= 512 ? 2 : 3));
+    const int per = ds2_cdiv(nstep, ks), nsplit = ds2_cdiv(nstep, per);
+    if (nsplit > 1 && !(zeroed && *zeroed)) {
+        (void)hipMemsetAsync(out, 0, o_elems * sizeof(float), st);
+        if (zeroed) *zeroed = true;
+    }
+    dim3 grid(tiles, nsplit), block(256);
+    const int at = nsplit > 1 ? 1 : 0;
+#define DS2_GATHER_GO(P_, N_)                                                                                            \
+    hipLaunchKernelGGL((conv2_gather_kernel<P_, N_>), grid, block, 0, st, A, a_bytes, tab, Wp, w_bytes, bias, out, g, per, at)
+    if (mode == 6 && nt == 2) DS2_GATHER_GO(6, 2);
+    else if (mode == 6) DS2_GATHER_GO(6, 1);
+    else if (nt == 2) DS2_GATHER_GO(9, 2);
+    else DS2_GATHER_GO(9, 1);
+#undef DS2_GATHER_GO
 }
 
 }  // namespace
@@ -298,18 +320,9 @@ int ds2_conv2_fwd_split(const float* in, const float* weight, const float* bias,
     g.o_b_stride = 32 * 21 * tout;
     g.o_row_stride = tout;
     g.o_col_stride = 21 * tout;
-    const int tiles = ds2_cdiv(g.M, 256), nstep = NP * NG;
-    const int ks = pick_ksplit(tiles);
-    const int per = ds2_cdiv(nstep, ks), nsplit = ds2_cdiv(nstep, per);
-    if (nsplit > 1) (void)hipMemsetAsync(out, 0, o_elems * sizeof(float), st);
+    const int nstep = NP * NG;
     const unsigned int w_bytes = (unsigned int)((NP * NG + SPARE) * 3 * 32 * 16 * 2);
-    dim3 grid(tiles, nsplit), block(256);
-    if (mode == 6)
-        hipLaunchKernelGGL((conv2_gather_kernel<6>), grid, block, 0, st, in, (unsigned int)a_bytes, tap_off, Wp, w_bytes, bias,
-                           out, g, per, nsplit > 1 ? 1 : 0);
-    else
-        hipLaunchKernelGGL((conv2_gather_kernel<9>), grid, block, 0, st, in, (unsigned int)a_bytes, tap_off, Wp, w_bytes, bias,
-                           out, g, per, nsplit > 1 ? 1 : 0);
+    launch_gather(mode, in, (unsigned int)a_bytes, tap_off, Wp, w_bytes, bias, out, o_elems, g, nstep, nullptr, st);
     return 0;
 }
 
@@ -359,21 +372,9 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
         g.o_b_stride = 32 * 61 * t1;
         g.o_row_stride = 2 * t1;
         g.o_col_stride = 61 * t1;
-        const int tiles = ds2_cdiv(g.M, 256), nstep = 16 * ng;
-        const int ks = pick_ksplit(tiles);
-        const int per = ds2_cdiv(nstep, ks), nsplit = ds2_cdiv(nstep, per);
-        if (nsplit > 1 && !zeroed) {
-            (void)hipMemsetAsync(d_in, 0, o_elems * sizeof(float), st);
-            zeroed = true;
-        }
         const unsigned int w_bytes = (unsigned int)((16 * ng + SPARE) * 3 * 32 * 16 * 2);
-        dim3 grid(tiles, nsplit), block(256);
-        if (mode == 6)
-            hipLaunchKernelGGL((conv2_gather_kernel<6>), grid, block, 0, st, dyp, (unsigned int)a_bytes, tab + 512 * par, Wp[par],
-                               w_bytes, (const float*)nullptr, d_in, g, per, nsplit > 1 ? 1 : 0);
-        else
-            hipLaunchKernelGGL((conv2_gather_kernel<9>), grid, block, 0, st, dyp, (unsigned int)a_bytes, tab + 512 * par, Wp[par],
-                               w_bytes, (const float*)nullptr, d_in, g, per, nsplit > 1 ? 1 : 0);
+        launch_gather(mode, dyp, (unsigned int)a_bytes, tab + 512 * par, Wp[par], w_bytes, nullptr, d_in, o_elems, g, 16 * ng,
+                      &zeroed, st);
     }
     return 0;
 }
