@@ -257,7 +257,7 @@ int conv_split_mode() {
 
 // Work decomposition.  A wave owns 64 positions (two row tiles sharing the filter fragments) when that still gives every
 // SIMD about two waves, else 32; when even those are fewer than the chip's 1024 SIMDs (a short minibatch), K is split over
-// workgroups too (float atomics into a zeroed output).  Measured, B = 10, forward, ms (64 positions: 1 / 2 splits):
+// workgroups too in the data gradient (float atomics into a zeroed output).  Measured, B = 10, forward, ms (64 positions: 1 / 2 splits):
 // T_in = 200 0.211 / 0.155, 300 0.217 / 0.187, 500 0.232 / 0.252, 830 0.343 / 0.391, 1501 0.559 / 0.633 -- at 830 the
 // 1332 waves leave a SIMD with one or two of them and the kernel takes the time of two.
 void launch_gather(int mode, const float* A, unsigned int a_bytes, const int* tab, const unsigned int* Wp, unsigned int w_bytes,
@@ -268,11 +268,13 @@ void launch_gather(int mode, const float* A, unsigned int a_bytes, const int* ta
     const int waves64 = ds2_cdiv(g.M, 64);
     const int nt = force_nt > 0 ? force_nt : (waves64 >= 1536 ? 2 : 1);   // (B = 10: T_in 500 0.217 / 0.252 ms with 32 / 64, 830 a tie, 1100 0.469 / 0.403)
     const int tiles = ds2_cdiv(g.M, 128 * nt), waves = tiles * 4;
-    const int ks = force_ks > 0 ? force_ks : (waves >= 1024 ? 1 : (waves >= 512 ? 2 : 3));
+    // (the forward pass passes zeroed == nullptr and is never split: float atomics would make its output -- and with it every
+    // activation, eval included -- vary in the last bits from run to run)
+    const int ks = !zeroed ? 1 : (force_ks > 0 ? force_ks : (waves >= 1024 ? 1 : (waves >= 512 ? 2 : 3)));
     const int per = ds2_cdiv(nstep, ks), nsplit = ds2_cdiv(nstep, per);
-    if (nsplit > 1 && !(zeroed && *zeroed)) {
+    if (nsplit > 1 && !*zeroed) {
         (void)hipMemsetAsync(out, 0, o_elems * sizeof(float), st);
-        if (zeroed) *zeroed = true;
+        *zeroed = true;
     }
     dim3 grid(tiles, nsplit), block(256);
     const int at = nsplit > 1 ? 1 : 0;

@@ -200,6 +200,26 @@ def test_full_size_step_properties():
     np.testing.assert_allclose(probs.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize('bsz,t_in', [(3, 181), (10, 400), (2, 1001)])
+def test_forward_pass_is_bitwise_reproducible(bsz, t_in):
+    """No float atomics on the forward path: eval outputs and the training-mode logits are bit-identical from call to call
+    (the greedy transcript of an utterance must not depend on the run).  Short inputs matter: the conv2 gather kernel and
+    the GEMMs split K over workgroups only in the backward pass."""
+    from codes.model import DeepSpeech
+    torch.manual_seed(11)
+    model = DeepSpeech().to('cuda')
+    x = torch.randn(bsz, t_in, 161, device='cuda')
+    model.eval()
+    with torch.no_grad():
+        a = model(x)
+        b = model(x)
+    assert torch.equal(a, b)
+    model.train()
+    acts0, _ = model._forward_impl(x.contiguous().float(), training=True, need_grad=False)
+    acts1, _ = model._forward_impl(x.contiguous().float(), training=True, need_grad=False)
+    assert torch.equal(acts0, acts1)
+
+
 def test_deferred_readback_gives_the_same_steps():
     """``Trainer.update(defer=True)`` (the host reads step i's loss after enqueuing step i + 1) against the synchronous
     form: same losses, gradient norm and parameters; ``run()`` reports every step exactly once."""
@@ -237,7 +257,7 @@ def test_deferred_readback_gives_the_same_steps():
     # changes from run to run -- two synchronous runs differ in the last bits too)
     for losses, norm, params, it in runs[1:]:
         np.testing.assert_allclose(losses, runs[0][0], rtol=1e-5)
-        np.testing.assert_allclose(norm, runs[0][1], rtol=1e-5)
+        np.testing.assert_allclose(norm, runs[0][1], rtol=3e-5)          # (the fourth step's: three updates of atomic noise)
         assert it == len(batches)
         for a, b in zip(params, runs[0][2]):
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6)
