@@ -246,7 +246,7 @@ def test_conv2_wgrad_lds_form_repeatable_at_training_size(ops, monkeypatch):
 @pytest.mark.parametrize('bsz,t1', [(2, 56), (1, 33), (3, 129), (10, 150), (6, 400), (2, 1501 // 2)])
 def test_conv2_forward_families_agree(ops, monkeypatch, bsz, t1):
     """conv2's forward pass three ways against torch: the gather kernel on the bf16 matrix pipe (default; 6 and 9 partial
-    products; one to three K splits depending on the number of positions) and the two direct kernels on the f32-input
+    products; 32 or 64 positions per wave depending on the number of positions) and the two direct kernels on the f32-input
     matrix instruction.  Error relative to sum |w||x| as in the GEMM family test: the split kernels no worse than the
     direct ones."""
     torch.manual_seed(bsz * 1000 + t1)

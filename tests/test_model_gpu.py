@@ -253,14 +253,21 @@ def test_deferred_readback_gives_the_same_steps():
             assert [i for i, _ in seen] == list(range(len(batches)))
             losses = [v for _, v in seen]
         runs.append((losses, tr.last_grad_norm, [p.detach().clone() for p in model.parameters()], tr.iteration))
-    # (not bit-for-bit: the split-K weight-gradient GEMMs add their partial products with float atomics, in an order that
-    # changes from run to run -- two synchronous runs differ in the last bits too)
+    # Not bit-for-bit: the split-K weight-gradient GEMMs add their partial products with float atomics, in an order that
+    # changes from run to run -- two synchronous runs differ in the last bits too.  And the last bits decide on which side of
+    # the conv block's hard clip an activation within 1e-7 of the boundary falls (tools/clip_boundary_probe.py): one such flip
+    # moves one output channel's conv filter gradient by a few per cent.  So: the first step tightly (same weights), later
+    # steps and the parameters with room for a flip -- a step reported twice, skipped or applied out of order would be off by
+    # orders of magnitude more.
     for losses, norm, params, it in runs[1:]:
-        np.testing.assert_allclose(losses, runs[0][0], rtol=1e-5)
-        np.testing.assert_allclose(norm, runs[0][1], rtol=3e-5)          # (the fourth step's: three updates of atomic noise)
+        np.testing.assert_allclose(losses[0], runs[0][0][0], rtol=1e-6)
+        np.testing.assert_allclose(losses, runs[0][0], rtol=1e-4)
+        np.testing.assert_allclose(norm, runs[0][1], rtol=1e-3)
         assert it == len(batches)
         for a, b in zip(params, runs[0][2]):
-            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6)
+            d = (a - b).abs()
+            assert float(d.max()) <= 1e-4
+            assert float((d > 2e-6).float().mean()) <= 0.01
 
 
 def test_beam_decoder_agrees_with_greedy_on_confident_outputs():
