@@ -639,9 +639,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(int M, int N, int K
 //
 // Every fp32 operand element is written as a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
 // (round-to-nearest-even at each step; bf16 has fp32's exponent range and 8 significant bits, so the three terms carry all
-// 24 bits of a: |a2| <= 2^-9 |a|, |a3| <= 2^-18 |a|, a - a1 - a2 - a3 = 0 barring underflow).  A product a b is then the sum
+// 24 bits of a: |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a|, a - a1 - a2 - a3 = 0 barring underflow).  A product a b is then the sum
 // of nine partial products ai bj, each EXACT in the pipe's fp32 accumulator (8 x 8 significant bits).  NPROD = 9 adds all
-// of them; NPROD = 6 leaves out a2 b3, a3 b2 and a3 b3, together <= 2^-26 |a b| -- a quarter of the rounding error of ONE
+// of them; NPROD = 6 leaves out a2 b3, a3 b2 and a3 b3, together below the rounding error of ONE
 // fp32 product, and far below what the fp32 accumulation of K such products leaves in either kernel family.  The
 // accumulator is fp32 as in the f32-input MFMA kernels above.  v_mfma_f32_32x32x16_bf16 runs 16x the f32-input MFMA's
 // rate, so six of them per 16 k are 2.7x the f32 pipe's peak for the same fp32 result (tests/test_kernels_gpu.py checks

@@ -1,9 +1,11 @@
 // fp32 products on the bf16 matrix pipe: error-free three-way operand splitting (shared by gemm.hip and conv_split.hip).
 //
 // a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2), round-to-nearest-even at each step: bf16 has
-// fp32's exponent range and 8 significant bits, so the three terms carry all 24 bits of a (|a2| <= 2^-9 |a|,
-// |a3| <= 2^-18 |a|).  A product a b is the sum of nine partial products ai bj, each EXACT in the matrix instruction's fp32
-// accumulator; the kernels add six of them (a2 b3 + a3 b2 + a3 b3 <= 2^-26 |a b| is left out) or all nine.
+// fp32's exponent range and 8 significant bits, so the three terms carry all 24 bits of a (|a2| <= 2^-8 |a|,
+// |a3| <= 2^-16 |a|).  A product a b is the sum of nine partial products ai bj, each EXACT in the matrix instruction's fp32
+// accumulator; the kernels add six of them or all nine.  The three left out, a2 b3 + a3 b2 + a3 b3, are bounded by
+// 2^-23 |a b| in the worst case of both bounds; over 10^6 random products the six-product sum is off by at most 2^-24.2 |a b|
+// and 5.8e-9 rms -- a correctly rounded fp32 multiply is off by up to 2^-24 and 2.5e-8 rms (tests/test_split_cpu.py).
 #pragma once
 #include "ds2_common.h"
 

@@ -91,7 +91,8 @@ int ds2_gain_requantize(const float* x, const int64_t* offsets, const float* gai
  *   mode 6 / 9  every fp32 operand element is split without error into three bf16 terms a = a1 + a2 + a3
  *               (round-to-nearest at each step: the three 8-bit significands carry all 24 bits), and a * b is summed from
  *               partial products ai * bj on the bf16 matrix instruction, each exact in its fp32 accumulator.  Mode 9 adds
- *               all nine; mode 6 (the default) leaves out a2 b3 + a3 b2 + a3 b3 <= 2^-26 |a b|, a quarter of one fp32
+ *               all nine; mode 6 (the default) leaves out a2 b3 + a3 b2 + a3 b3: at most 2^-24.2 |a b| and 6e-9 rms over 10^6 random
+ *               products (tests/test_split_cpu.py), where a correctly rounded fp32 multiply is off by up to 2^-24 and 2.5e-8 rms -- less than one fp32
  *               rounding.  Measured against fp64 the three agree to the last digit shown (tools/gemm_split_check.py:
  *               max error / sum|a||b| 2.9e-7 at K = 672 in modes 6 and 9, 3.2e-7 in mode 0).  Not handled like mode 0:
  *               an operand element beyond bf16's largest finite value (3.39e38) or an infinity gives NaN, and terms below

@@ -4,7 +4,7 @@ An fp32 value a is written a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1)
 round-to-nearest-even (what v_cvt_pk_bf16_f32 does).  Claims the kernels rely on:
   (1) the split is error-free: a1 + a2 + a3 == a exactly, for every finite fp32 whose third term does not underflow;
   (2) |a2| <= 2^-8 |a| and |a3| <= 2^-16 |a| (so the left-out products a2 b3 + a3 b2 + a3 b3 are <= 2^-24 (1 + 2^-8) |a b| in
-      the worst case of both bounds, and ~2^-26 |a b| typically);
+      the worst case of both bounds, and ~2^-29 |a b| typically);
   (3) every partial product ai bj has at most 16 significant bits: exact in an fp32 accumulator;
   (4) six partial products reproduce a b to a relative error below one fp32 rounding (2^-24)."""
 import numpy as np
