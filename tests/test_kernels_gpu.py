@@ -454,6 +454,18 @@ def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch, bsz
     _long_sequence_case(ops, monkeypatch, bsz, 3 if bsz <= 12 else 2)
 
 
+@pytest.mark.parametrize('bsz,fwd_bf16,bwd_bf16', [(17, '0', '0'), (32, '0', '0'), (64, '0', '0'), (17, '1', '1'), (32, '1', '1'),
+                                                   (64, '1', '1')])
+def test_gru_two_part_forms_f32_and_split_operand_families(ops, monkeypatch, bsz, fwd_bf16, bwd_bf16):
+    """The two-part 16x16 recurrences (B >= 17) in both arithmetic families against the launch-per-step kernels: the
+    f32-input MFMA forms (the default backward form; the forward one is DS2_GRU_P2_BF16=0) and the split-operand forms on the
+    bf16 matrix pipe (the default forward form; the backward twin is DS2_GRU_P2_BF16_BWD=1), whose new state crosses the
+    exchange ring as three bf16 planes."""
+    monkeypatch.setenv('DS2_GRU_P2_BF16', fwd_bf16)
+    monkeypatch.setenv('DS2_GRU_P2_BF16_BWD', bwd_bf16)
+    _long_sequence_case(ops, monkeypatch, bsz, 1)
+
+
 _co_resident = {}
 
 
