@@ -1249,7 +1249,7 @@ constexpr int RED4_PITCH = NWP * 4 + 4;   // floats per reduced value in LDS: 32
 // per step and waits for 50 / 34 producers instead of 100.  The launcher picks the form with a cost model fitted to
 // measurements: a step costs ~0.40 us per (batch quad x 8 units) of MFMA + fold work and ~0.34 us per 4 batch rows
 // of hand-off loads per workgroup.
-template <int NGI, int NRG, int PROTO>
+template <int NGI, int NRG, int PROTO, int NP = NRG / 2>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        const float* __restrict__ hout,
                                                                        const float* __restrict__ d_out,
@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     // per step), and the pitch of 36 puts the 16 storing lanes of a fold (4 rows x 4 j) on 16 different banks
     extern __shared__ __attribute__((aligned(16))) float red4[];
     __shared__ int abort_flag;
-    constexpr int NPART = NRG / 2;                      // batch parts
+    constexpr int NPART = NP;                           // batch parts (NRG / 2, or 3 with NRG = 7: the 174-workgroup form)
     constexpr int UNITS = 4 * NRG;                      // hidden units per workgroup
     constexpr int CGW = NRG == 2 ? CGC : (NRG == 4 ? 2 : 1);   // batch quads per chunk (register budget)
 
@@ -2081,23 +2081,23 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
     return false;
 }
 
-template <int NRG, int PROTO>
+template <int NRG, int PROTO, int NP = NRG / 2>
 bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                             SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3, 5};
     const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
-    constexpr int NPART = NRG / 2;
+    constexpr int NPART = NP;
     dim3 grid(ds2_cdiv(H, 4 * NRG), 2, NPART), block(NWP * 64);
     const int ncg = (ds2_cdiv(B, NPART) + 3) / 4;
     const size_t lds = (size_t)NRG * ncg * 16 * RED4_PITCH * sizeof(float);
 #define DS2_BWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K, NRG, PROTO>),              \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_bwd_persistent4_kernel<K, NRG, PROTO, NP>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return false;                                                                                        \
-        if (!grid_is_coresident(&gru_bwd_persistent4_kernel<K, NRG, PROTO>, grid, lds)) return false;                   \
-        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K, NRG, PROTO>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t,    \
+        if (!grid_is_coresident(&gru_bwd_persistent4_kernel<K, NRG, PROTO, NP>, grid, lds)) return false;                   \
+        hipLaunchKernelGGL((gru_bwd_persistent4_kernel<K, NRG, PROTO, NP>), grid, block, lds, st, G, ghn, hout, d_out, w_hh_t,    \
                            sync, ring, T, B, H, dbg, spec_timing(1));                                                            \
         return true;
     switch (ngi) {
@@ -2334,6 +2334,8 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
                                       : launch_bwd_persistent_p2b<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
                  : ((B + 1) / 2 <= 16 ? launch_bwd_persistent_p2<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
                                       : launch_bwd_persistent_p2<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st));
+    else if (use4 && ngi_ok && parts == 3 && proto != 0 && getenv("DS2_GRU_BWD_WIDE") && getenv("DS2_GRU_BWD_WIDE")[0] == '1')
+        ok = launch_bwd_persistent4<7, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);   // 28 units: 174 CUs
     else if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);
