@@ -424,18 +424,27 @@ def main():
         dt_sync = float(ts[0])
     note('sync-per-step leg done: %.2f ms/step' % (1e3 * dt_sync / args.steps))
 
-    # the same steps with every GEMM on the f32-input MFMA kernels (ds2_gemm_split_mode 0) instead of the default
-    # split-operand kernels on the bf16 matrix pipe: both families take fp32 operands and return fp32-accurate products
+    # the same steps with every GEMM, conv2's forward pass and (B >= 17) the forward recurrence on the f32-input MFMA kernels
+    # (ds2_gemm_split_mode 0, DS2_CONV_SPLIT=0, DS2_GRU_P2_BF16=0) instead of the default split-operand kernels on the bf16
+    # matrix pipe: both families take fp32 operands and return fp32-accurate products
     # (include/ds2hip.h), this leg says what the choice of kernel family is worth
     from ds2hip import ops as _ops
     gemm_mode = _ops.gemm_split_mode()
     dt_f32 = None
     if gemm_mode != 0:
         _ops.gemm_split_mode(0)
+        saved_env = {k: os.environ.get(k) for k in ('DS2_CONV_SPLIT', 'DS2_GRU_P2_BF16')}
+        os.environ['DS2_CONV_SPLIT'] = '0'           # (read per call by the library: conv2 forward on the direct kernels,
+        os.environ['DS2_GRU_P2_BF16'] = '0'          # the B >= 17 forward recurrence on the f32-input form)
         try:
             dt_f32, _, _ = timed_steps(lambda i: step(i + args.warmup - 2), args.steps, 2, use_dist)   # the same bins
         finally:
             _ops.gemm_split_mode(gemm_mode)
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         if use_dist:
             ts = torch.tensor([dt_f32], dtype=torch.float64, device=dev)
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
@@ -566,6 +575,7 @@ def main():
                                 'correctly rounded fp32 multiply: 2^-24 and 2.5e-8): error against fp64 equal to the f32-input MFMA '
                                 'kernels\' (tests/test_kernels_gpu.py, tools/gemm_split_check.py)' % gemm_mode)
                                if gemm_mode else 'f32-input MFMA kernels (v_mfma_f32_32x32x2_f32)',
+                       'kernels_on_the_bf16_pipe': 'GEMMs, conv2 forward, forward recurrence from B = 17',
                        'same_steps_on_f32_input_mfma_gemms': None if dt_f32 is None else {
                            'frames_per_s': round(frames / dt_f32, 1), 'ms_per_step': round(1e3 * dt_f32 / args.steps, 3)}},
                    'persistent_to_step_fallbacks': (_fallbacks() if ddp is None
