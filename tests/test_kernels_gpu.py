@@ -510,11 +510,12 @@ def test_gru_persistent_long_sequence_narrow_forward_form(ops, monkeypatch):
     _long_sequence_case(ops, monkeypatch, 10, 2)
 
 
-@pytest.mark.parametrize('bsz', [8, 10])
+@pytest.mark.parametrize('bsz', [8, 10, 32])
 def test_gru_persistent_long_sequence_beside_a_streaming_kernel(ops, monkeypatch, bsz):
     """The same check with 32 workgroups of another kernel streaming HBM on a third stream the whole time (the condition
     of a data-parallel step, where RCCL's channel kernels run beside the recurrence, and of tools/interference_probe.py):
-    the speculative hand-off is timing dependent by design, so it is exercised under a neighbour's memory traffic too."""
+    the speculative hand-off is timing dependent by design, so it is exercised under a neighbour's memory traffic too
+    (B = 32: the counted protocol of the two-part forms, the forward one on the bf16 pipe)."""
     held = []
 
     def during():
