@@ -338,13 +338,15 @@ size_t ds2_conv2_dgrad_split_ws_floats(int B, int t1) {
 int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1, float* d_in, void* ws, hipStream_t st) {
     const int mode = conv_split_mode();
     if (mode == 0) return 1;
-    // Off by default: stand-alone it beats the direct kernel from T_in ~ 600 up (B = 10, ms: 830 0.398 / 0.491, 1100 0.561 /
-    // 0.594, 1501 0.718 / 0.774; 500 0.342 / 0.311, 200 0.267 / 0.194 -- three times the positions of the forward pass, half
-    // the taps, a padded copy of d(out) to make), but inside the training step, where the data gradient runs beside the
-    // side stream's bf16 GEMMs, it changed nothing (17.05 - 17.21 ms with and without, same box).  DS2_CONV_SPLIT_DGRAD=1
-    // selects it (read per call: the tests switch it).
+    // Stand-alone it beats the direct kernel from T_in ~ 600 up (B = 10, ms: 830 0.398 / 0.491, 1100 0.561 / 0.594, 1501 0.718 /
+    // 0.774) and loses below (500 0.342 / 0.311, 200 0.267 / 0.194: three times the positions of the forward pass, half the
+    // taps, a padded copy of d(out) to make).  Inside the training step it runs beside the side stream's bf16 GEMMs: always
+    // on, 240-step runs of the B = 10 bin mix: 16.58 / 16.63 / 16.67 ms against 16.77 / 16.78 / 16.74 with the direct kernel.
+    // DS2_CONV_SPLIT_DGRAD = 0 / 1 forces a choice (read per call: the tests switch it); default: from B * T1 >=
+    // DS2_CONV_SPLIT_DGRAD_MIN (3500) input columns.
     const char* on = getenv("DS2_CONV_SPLIT_DGRAD");
-    if (!(on && on[0] == '1')) return 1;
+    static const int dgrad_min = getenv("DS2_CONV_SPLIT_DGRAD_MIN") ? atoi(getenv("DS2_CONV_SPLIT_DGRAD_MIN")) : 3500;
+    if (on ? on[0] != '1' : (long)B * t1 < dgrad_min) return 1;
     const int T = t1 - 10, TP = T + 20;
     const unsigned long long a_bytes = 4ull * B * 32 * 41 * TP, o_elems = 1ull * B * 32 * 61 * t1;
     if (a_bytes >= 0x7FFFFFF0ull || o_elems >= 0x7FFFFFF0ull) return 1;

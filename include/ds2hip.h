@@ -124,7 +124,8 @@ int ds2_gemm_f32_tn_group(int count, const float* const* A_host, const int* lda_
  * ds2_conv2_dgrad_ws_floats(B, T1) floats -- its default form also keeps a zero-bordered copy of d_out there).
  * Arithmetic of conv2's forward pass and data gradient: fp32 operands, accumulator and result; by default the products run
  * on the bf16 matrix pipe after the error-free three-way operand split described at ds2_gemm_f32 (six exact partial
- * products; DS2_CONV_SPLIT=9 all nine, =0 the direct kernels on the f32-input matrix instruction).
+ * products; DS2_CONV_SPLIT=9 all nine, =0 the direct kernels on the f32-input matrix instruction; the data gradient takes
+ * that form from B * T1 >= 3500 input columns, DS2_CONV_SPLIT_DGRAD=0 / 1 forces a choice).
  */
 int ds2_transpose_btf_to_bft(const float* x, int B, int T, int F, float* x_t, void* stream);
 size_t ds2_conv_wt_ws_floats(int which);
