@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "ds2_common.h"
+#include "split_bf16.h"
 
 namespace {
 
@@ -652,25 +653,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(int M, int N, int K
 // is [row][plane][16 k] bf16 (row pitch 112 B: the 16-byte fragment reads of a 32-row tile are conflict-free) and a
 // wave's twelve fragments (2 row tiles + 2 column tiles, 3 planes each) feed 24 MFMAs.
 // ----------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-constexpr int SP = 112;                         // LDS row pitch, bytes: 3 planes x 16 k x 2 B + 16
+constexpr int SP = SPLIT_PITCH;                 // LDS row pitch, bytes: 3 planes x 16 k x 2 B + 16 (split_bf16.h)
 constexpr int SPLIT_TILE_BYTES = 128 * SP;      // one operand slab
-
-__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
-    unsigned int v;                             // round to nearest even, lo -> bits 15:0, hi -> bits 31:16
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(v) : "v"(lo), "v"(hi));
-    return v;
-}
-// two fp32 values -> three dwords of packed bf16 pairs (planes 1, 2, 3)
-__device__ __forceinline__ void split3(float a, float b, unsigned int& p1, unsigned int& p2, unsigned int& p3) {
-    p1 = pack_bf16(a, b);
-    float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
-    p2 = pack_bf16(ra, rb);
-    ra -= __builtin_bit_cast(float, p2 << 16);
-    rb -= __builtin_bit_cast(float, p2 & 0xffff0000u);
-    p3 = pack_bf16(ra, rb);
-}
 
 // Prefetch registers of one operand slab: 8 floats per thread.
 //   k-contiguous source: r[4 i + c] = element (x = tid / 4 + 64 i, k = 4 (tid & 3) + c)        (two 16-byte loads)
@@ -801,19 +785,7 @@ __device__ __forceinline__ void gemm_split_tile_body(char (&lds)[2][2][SPLIT_TIL
         for (int i = 0; i < NI_; ++i)
 #pragma unroll
             for (int j = 0; j < NJ_; ++j) {
-                f32x16 c = acc[i][j];
-                if (NPROD == 9) {
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][1], c, 0, 0, 0);
-                }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-                acc[i][j] = c;
+                acc[i][j] = split_mfma<NPROD>(a[i], b[j], acc[i][j]);
             }
         // (unconditional as well: behind the last slab it fills a buffer nobody reads)
         split_store<A_KCONTIG>(lds[cur ^ 1][0], tid, ra[cur ^ 1]);

@@ -29,22 +29,6 @@ __device__ __forceinline__ void split3(float a, float b, unsigned int& p1, unsig
     rb -= __builtin_bit_cast(float, p2 & 0xffff0000u);
     p3 = pack_bf16(ra, rb);
 }
-// eight consecutive k of one row -> the row's three 16-byte runs
-__device__ __forceinline__ void split_store_row8(char* __restrict__ row, const float (&r)[8]) {
-    unsigned int p[3][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) split3(r[2 * c], r[2 * c + 1], p[0][c], p[1][c], p[2][c]);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint4*>(row + 32 * q) = make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]);
-}
-// four consecutive k of one row -> 8 bytes in each of the row's three planes
-__device__ __forceinline__ void split_store_row4(char* __restrict__ row, float r0, float r1, float r2, float r3) {
-    unsigned int p[3][2];
-    split3(r0, r1, p[0][0], p[1][0], p[2][0]);
-    split3(r2, r3, p[0][1], p[1][1], p[2][1]);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(row + 32 * q) = make_uint2(p[q][0], p[q][1]);
-}
 // the six (or nine) partial products of one 32 x 32 x 16 step
 template <int NPROD>
 __device__ __forceinline__ f32x16 split_mfma(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
