@@ -198,6 +198,7 @@ class Trainer(object):
             ops.clip_sgd_nesterov(model._flat_p[lo:hi], gflat[lo:hi], self._buf[lo:hi], self._sumsq, scale,
                                   self.max_norm, g['lr'], g['momentum'], self._first)
         self._first = False
+        model._tick('gradient norm + clip + Nesterov SGD')
         # one launch gathers what the host needs (loss sum, grad norm^2, sticky kernel-timeout flags, inf count),
         # one device->host copy brings it over
         self._stats = ops.step_stats(costs, self._sumsq, self._stats)

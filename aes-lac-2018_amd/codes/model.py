@@ -223,6 +223,17 @@ class DeepSpeech(nn.Module):
                 return gflat[o:o + p.numel()].view(p.shape)
         raise KeyError('parameter not in flat buffer')
 
+    # ------------------------------------------------------------------ chain timing (bench.py's live time-share table)
+    def _tick(self, name):
+        """Phase boundary on the main stream.  A no-op unless ``self._ticks`` is a list (bench.py sets it for one step):
+        then a timing event is recorded, and the elapsed time between consecutive events is the CHAIN time of the phase
+        that ends here (waits for the side stream included)."""
+        ticks = self.__dict__.get('_ticks')
+        if ticks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            ticks.append((name, ev))
+
     # ------------------------------------------------------------------ forward
     def forward(self, x):
         dev = self.conv[0].weight.device
@@ -260,6 +271,7 @@ class DeepSpeech(nn.Module):
         for mod in mods:
             if getattr(mod, 'frozen_stats', False):
                 raise NotImplementedError('freezing BatchNorm statistics is supported for the conv block only')
+        self._tick('start')
         xt = ops.transpose_btf(x)                                                   # (B,161,T_in)
         y1 = ops.conv_fwd(1, xt, c[0].weight, c[0].bias, t_in)                      # (B,32,61,T1)
         mi1 = ops.bn2d_stats(y1, c[1].running_mean, c[1].running_var, conv_train)
@@ -272,6 +284,7 @@ class DeepSpeech(nn.Module):
             c[4].num_batches_tracked += 1
         sv['conv_frozen'] = conv_frozen
         sv.update(xt=xt, y1=y1, mi1=mi1, a1=a1, y2=y2, mi2=mi2)
+        self._tick('conv block forward (transpose, conv1, conv2, 2 x BatchNorm + clip)')
         rows = t * bsz
         layers = []
         prev_h = None
@@ -306,7 +319,9 @@ class DeepSpeech(nn.Module):
             w_ih = self._pair(r.weight_ih_l0, r.weight_ih_l0_reverse)               # (6H, In) view
             w_hh = self._pair(r.weight_hh_l0, r.weight_hh_l0_reverse)               # (2*3H, H) view
             gates = ops.gemm(xin.view(rows, n_in), w_ih, trans_b=True)              # (T*B, 6H)
+            self._tick('BatchNorm + input projection GEMM (forward)')
             ghn, hout = ops.gru_bidir_fwd(gates, w_hh, t, bsz, hid)
+            self._tick('BiGRU recurrence forward')
             rec.update(xin=xin, gates=gates, ghn=ghn, hout=hout)
             layers.append(rec)
             prev_h = hout
@@ -316,6 +331,7 @@ class DeepSpeech(nn.Module):
         if training:
             head[0].num_batches_tracked += 1
         acts = ops.gemm(xf, head[1].weight, trans_b=True).view(t, bsz, self._num_classes)
+        self._tick('head: BatchNorm + FC (forward)')
         sv.update(layers=layers, mi_fc=mi, xf=xf)
         return acts, (sv if need_grad else None)
 
@@ -350,6 +366,7 @@ class DeepSpeech(nn.Module):
         # everything the forward pass put on the side stream (the trainer's one fill of ``gflat``, the W_hh transposes) is
         # complete before the first gradient is written
         main = torch.cuda.current_stream()
+        self._tick('CTC loss + gradient')
         main.wait_event(sv['w_hh_t_ready'])
         head = self.fc[0].module
         d2 = d_acts.reshape(rows, ncls)
@@ -360,6 +377,7 @@ class DeepSpeech(nn.Module):
                           gv(head[0].bias))
         if grad_ready is not None:
             grad_ready(*self._span(head[0].weight, head[1].weight))
+        self._tick('head: FC + BatchNorm (backward)')
         nl = len(sv['layers'])
         f4 = 4
         # The weight-gradient GEMMs of a layer (dW_ih, dW_hh) are not on the chain that feeds the next (lower) layer:
@@ -386,21 +404,25 @@ class DeepSpeech(nn.Module):
             # The dX GEMM below splits K and adds its partial products with atomics, so its output must start from zero: the
             # fill (16 MB) is issued on the SIDE stream in front of the recurrence launch and runs beside it, instead of on
             # the chain behind it (where, sharing the chip with the side stream's dW_ih GEMM, it took ~30 us per layer)
+            # -- on its OWN normal-priority stream: the chain waits for this fill, and behind the low-priority weight-gradient
+            # stream's backlog (large batches, or RCCL channel kernels sharing the chip) that wait would be a priority inversion
             dx_buf, dx_ready = None, None
             if side is not None:
+                fill = self._fill_stream(gflat.device)
                 dx_buf = torch.empty((rows, n_in), dtype=gates.dtype, device=gates.device)
-                dx_buf.record_stream(side)
+                dx_buf.record_stream(fill)
                 alloc_ev = torch.cuda.Event()
                 alloc_ev.record(main)
-                side.wait_event(alloc_ev)
-                with torch.cuda.stream(side):
+                fill.wait_event(alloc_ev)
+                with torch.cuda.stream(fill):
                     dx_buf.zero_()
                     dx_ready = torch.cuda.Event()
-                    dx_ready.record(side)
+                    dx_ready.record(fill)
             if pending is not None:
                 gate = torch.cuda.Event()
                 gate.record(main)
             ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid)           # gates -> d(gi), ghn -> d(gh_n)
+            self._tick('BiGRU recurrence backward (weight-gradient GEMMs beside it)')
             if pending is not None:
                 pending(gate)
                 pending = None
@@ -457,6 +479,7 @@ class DeepSpeech(nn.Module):
                                   gv(bn.bias))
             else:
                 dy = dxin
+            self._tick('dX GEMM + BatchNorm (backward)')
             if side is not None and self.defer_wgrad:
                 pending = wgrad                    # released behind the next layer's recurrence launch
             else:
@@ -488,8 +511,10 @@ class DeepSpeech(nn.Module):
         d_a1 = ops.conv2_dgrad(d_y2, c[3].weight, t1)
         d_y1 = ops.bn2d_htanh_bwd(sv['y1'], d_a1, sv['mi1'], c[1].weight, c[1].bias, gv(c[1].weight), gv(c[1].bias))
         ops.conv_wgrad(1, sv['xt'], d_y1, t_in, gv(c[0].weight), gv(c[0].bias))
+        self._tick('conv block backward (main stream)')
         if side is not None:
             main.wait_stream(side)                  # every later consumer of the gradients sits behind this join
+            self._tick('tail: waiting for the side stream (bottom layer dW, conv2 wgrad)')
         keepalive.clear()
         if grad_ready is not None:
             grad_ready(*self._span(c[0].weight, c[4].bias))
@@ -503,6 +528,14 @@ class DeepSpeech(nn.Module):
             else:
                 st = torch.cuda.Stream(device=dev)
             self._side = st
+        return st
+
+    def _fill_stream(self, dev):
+        """Normal-priority stream for the dX buffers' zero fills (they run beside the recurrence launch; the chain waits for
+        them, so they must not queue behind the low-priority weight-gradient stream's backlog)."""
+        st = self.__dict__.get('_fill')
+        if st is None or st.device != dev:
+            st = self.__dict__['_fill'] = torch.cuda.Stream(device=dev)
         return st
 
     def _pair_view(self, gflat, p_fwd, p_rev):

@@ -673,10 +673,13 @@ extern "C" size_t ds2_conv2_dgrad_ws_floats(int B, int T1) {
 }
 
 extern "C" int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, int T1, float* d_in, float* wt_ws,
-                               void* stream) {
+                               size_t ws_floats, void* stream) {
     DS2_CHECK_ARG(d_out && weight && d_in && wt_ws && B > 0 && T1 > 10);
+    DS2_CHECK_ARG(ws_floats >= ds2_conv_wt_ws_floats(2));
     hipStream_t st = (hipStream_t)stream;
-    if (ds2_conv2_dgrad_split(d_out, weight, B, T1, d_in, wt_ws, st) == 0) {      // gather-GEMM, conv_split.hip
+    // the gather form needs room for its zero-bordered copy of d_out: an undersized workspace selects the direct kernel
+    if (ws_floats >= ds2_conv2_dgrad_split_ws_floats(B, T1) &&
+        ds2_conv2_dgrad_split(d_out, weight, B, T1, d_in, wt_ws, st) == 0) {      // gather-GEMM, conv_split.hip
         DS2_CHECK_LAUNCH();
         return DS2_OK;
     }

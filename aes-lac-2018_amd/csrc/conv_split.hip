@@ -260,22 +260,39 @@ int conv_split_mode() {
 // workgroups too in the data gradient (float atomics into a zeroed output).  Measured, B = 10, forward, ms (64 positions: 1 / 2 splits):
 // T_in = 200 0.211 / 0.155, 300 0.217 / 0.187, 500 0.232 / 0.252, 830 0.343 / 0.391, 1501 0.559 / 0.633 -- at 830 the
 // 1332 waves leave a SIMD with one or two of them and the kernel takes the time of two.
+struct GatherPlan {
+    int nt, tiles, per, nsplit;
+};
+// (the forward pass is never split over K: float atomics would make its output -- and with it every activation, eval included
+// -- vary in the last bits from run to run)
+GatherPlan plan_gather(int M, int nstep, bool may_split) {
+    static const int force_ks = getenv("DS2_CONV_SPLIT_KS") ? atoi(getenv("DS2_CONV_SPLIT_KS")) : 0;
+    static const int force_nt = getenv("DS2_CONV_SPLIT_NT") ? atoi(getenv("DS2_CONV_SPLIT_NT")) : 0;
+    GatherPlan p;
+    const int waves64 = ds2_cdiv(M, 64);
+    p.nt = force_nt > 0 ? force_nt : (waves64 >= 1536 ? 2 : 1);   // (B = 10: T_in 500 0.217 / 0.252 ms with 32 / 64, 830 a tie, 1100 0.469 / 0.403)
+    p.tiles = ds2_cdiv(M, 128 * p.nt);
+    const int waves = p.tiles * 4;
+    const int ks = !may_split ? 1 : (force_ks > 0 ? force_ks : (waves >= 1024 ? 1 : (waves >= 512 ? 2 : 3)));
+    p.per = ds2_cdiv(nstep, ks);
+    p.nsplit = ds2_cdiv(nstep, p.per);
+    return p;
+}
+
+// `zeroed`: nullptr = never split K (forward); else *zeroed must already be true when this launch splits (the CALLER clears the
+// output once, in front of its first launch, if ANY of its launches splits: the two row-parity launches of the data gradient
+// pick their split separately -- 31 against 30 rows per batch element can put them on either side of a threshold -- and a
+// fill issued by the second one would wipe the rows the first one has written).
 void launch_gather(int mode, const float* A, unsigned int a_bytes, const int* tab, const unsigned int* Wp, unsigned int w_bytes,
                    const float* bias, float* out, unsigned long long o_elems, const GatherGeom& g, int nstep, bool* zeroed,
                    hipStream_t st) {
-    static const int force_ks = getenv("DS2_CONV_SPLIT_KS") ? atoi(getenv("DS2_CONV_SPLIT_KS")) : 0;
-    static const int force_nt = getenv("DS2_CONV_SPLIT_NT") ? atoi(getenv("DS2_CONV_SPLIT_NT")) : 0;
-    const int waves64 = ds2_cdiv(g.M, 64);
-    const int nt = force_nt > 0 ? force_nt : (waves64 >= 1536 ? 2 : 1);   // (B = 10: T_in 500 0.217 / 0.252 ms with 32 / 64, 830 a tie, 1100 0.469 / 0.403)
-    const int tiles = ds2_cdiv(g.M, 128 * nt), waves = tiles * 4;
-    // (the forward pass passes zeroed == nullptr and is never split: float atomics would make its output -- and with it every
-    // activation, eval included -- vary in the last bits from run to run)
-    const int ks = !zeroed ? 1 : (force_ks > 0 ? force_ks : (waves >= 1024 ? 1 : (waves >= 512 ? 2 : 3)));
-    const int per = ds2_cdiv(nstep, ks), nsplit = ds2_cdiv(nstep, per);
-    if (nsplit > 1 && !*zeroed) {
+    const GatherPlan pl = plan_gather(g.M, nstep, zeroed != nullptr);
+    const int nt = pl.nt, tiles = pl.tiles, per = pl.per, nsplit = pl.nsplit;
+    if (nsplit > 1 && !*zeroed) {       // (not reached from ds2_conv2_dgrad_split, which fills up front; kept for other callers)
         (void)hipMemsetAsync(out, 0, o_elems * sizeof(float), st);
         *zeroed = true;
     }
+    (void)o_elems;
     dim3 grid(tiles, nsplit), block(256);
     const int at = nsplit > 1 ? 1 : 0;
 #define DS2_GATHER_GO(P_, N_)                                                                                            \
@@ -355,7 +372,11 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
     unsigned int* Wp[2] = {reinterpret_cast<unsigned int*>(ws) + 1024, reinterpret_cast<unsigned int*>(ws) + 1024 + img0};
     float* dyp = reinterpret_cast<float*>(ws) + 1024 + img0 + img1;
     hipLaunchKernelGGL(conv2_pad_dout_kernel, dim3(2048), dim3(256), 0, st, d_out, B, T, dyp);
+    // ONE decision about the zero fill for both row-parity launches, made before the first of them runs
     bool zeroed = false;
+    for (int par = 0; par < 2; ++par)
+        if (plan_gather(B * (par == 0 ? 31 : 30) * t1, 16 * tap_groups(par == 0 ? 11 : 10), true).nsplit > 1) zeroed = true;
+    if (zeroed) (void)hipMemsetAsync(d_in, 0, o_elems * sizeof(float), st);
     for (int par = 0; par < 2; ++par) {
         const int nrows = par == 0 ? 11 : 10, ng = tap_groups(nrows), RH = par == 0 ? 31 : 30;
         const int prep = (16 * ng + SPARE) * 32 * 2 * 4;

@@ -33,7 +33,7 @@ SIGNATURES = {
     'ds2_conv_wt_ws_floats': (_Z, [_I]),
     'ds2_conv_fwd': (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P]),
     'ds2_conv2_dgrad_ws_floats': (_Z, [_I, _I]),
-    'ds2_conv2_dgrad': (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    'ds2_conv2_dgrad': (_I, [_P, _P, _I, _I, _P, _P, _Z, _P]),
     'ds2_conv_wgrad': (_I, [_I, _P, _P, _I, _I, _P, _P, _P]),
     'ds2_bn_ws_bytes': (_Z, [_I]),
     'ds2_bn2d_stats': (_I, [_P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P]),
@@ -66,6 +66,8 @@ SIGNATURES = {
     'ds2_ctc_beam_search': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
 }
 
+ABI_VERSION = 400            # DS2_ABI_VERSION of include/ds2hip.h: the revision this table (and ops.py) is written against
+
 _lib = None
 
 ERR_ARG, ERR_LAUNCH, ERR_UNSUPPORTED = -1, -2, -3           # DS2_ERR_* of include/ds2hip.h
@@ -91,6 +93,11 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        have = lib.ds2_version()
+        if have != ABI_VERSION:
+            # signatures change between revisions without a change of symbol name: a stale binary would mis-pass arguments
+            raise RuntimeError('%s is ABI revision %d, this binding is written against %d (include/ds2hip.h DS2_ABI_VERSION) '
+                               '-- rebuild it: python aes-lac-2018_amd/csrc/build.py' % (LIB_PATH, have, ABI_VERSION))
         _lib = lib
     return _lib
 

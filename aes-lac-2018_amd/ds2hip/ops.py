@@ -279,7 +279,7 @@ def conv2_dgrad(d_out, weight, t1):
     bsz = d_out.shape[0]
     d_in = _empty((bsz, 32, 61, t1), d_out)
     ws = _empty((lib.query('ds2_conv2_dgrad_ws_floats', bsz, t1),), d_out)
-    lib.call('ds2_conv2_dgrad', d_out, weight, bsz, t1, d_in, ws)
+    lib.call('ds2_conv2_dgrad', d_out, weight, bsz, t1, d_in, ws, ws.numel())
     return d_in
 
 

@@ -80,6 +80,12 @@ def out_steps_of(bin_):
     return ((t_in + 9) // 2 - 9) * len(bin_[0])      # padded output steps actually computed
 
 
+def valid_out_steps_of(bin_):
+    """Output steps the utterances THEMSELVES have (each clip's own T = floor((T_in + 9) / 2) - 9): the algorithmic work.
+    ``out_steps_of`` counts what is computed (every utterance padded to the bin's longest clip)."""
+    return sum(((1 + len(w) // HOP) + 9) // 2 - 9 for w in bin_[0])
+
+
 def cpu_model_name():
     try:
         for line in open('/proc/cpuinfo'):
@@ -90,7 +96,42 @@ def cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline(plan, budget_s=60.0, full=True):
+def gpu_parity_side(model, trainer, front, decoder, plan_entry, dev):
+    """The HIP path's half of ``parity_vs_cpu_oracle``: on ONE bin (the longest of the corpus), from the model's CURRENT
+    weights -- eval-mode probabilities -> greedy strings, then one training step with the learning rate set to 0 (loss,
+    gradient norm; the weights stay put) and the train-mode logits.  Returns what cpu_baseline() needs to repeat it."""
+    from ds2hip import ops
+    bin_ = make_bin(plan_entry)
+    flat, offs, labels, lens = make_resident(bin_, dev)
+    trainer.flush()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().to('cpu').clone() for k, v in model.state_dict().items()}
+    model.eval()
+    with torch.no_grad():
+        inputs, pct = front(flat, offs)
+        probs = model(inputs)
+        sizes = (pct * probs.shape[1]).int()
+        strings, _ = decoder.decode(probs, sizes)
+    model.train()
+    lrs = [g['lr'] for g in trainer.optimizer.param_groups]
+    for g in trainer.optimizer.param_groups:
+        g['lr'] = 0.0
+    try:
+        loss = trainer.update((inputs, labels, pct, lens), defer=False)
+        gnorm = trainer.last_grad_norm
+        with torch.no_grad():
+            acts, _ = model._forward_impl(inputs, training=True, need_grad=False)
+    finally:
+        for g, lr in zip(trainer.optimizer.param_groups, lrs):
+            g['lr'] = lr
+    torch.cuda.synchronize()
+    ops.check_async_errors()
+    return {'state_dict': sd, 'plan_entry': plan_entry, 'logits': acts.transpose(0, 1).cpu().numpy(),
+            'loss_sum': float(loss) * len(bin_[0]), 'gnorm': float(gnorm), 'strings': [s[0] for s in strings],
+            'out_sizes': sizes.cpu().numpy(), 'labels_txt': None}
+
+
+def cpu_baseline(plan, budget_s=60.0, full=True, parity=None):
     """The oracle (stock PyTorch CPU ops, numerically the reference) timed on the host cores: full training steps
     (frontend -> fwd -> CTC -> bwd -> clip -> SGD) on B=10 bins of the SAME workload.  Protocol:
     2 untimed warm-up steps (the shortest bin), then timed steps on five bins spread evenly over the length range
@@ -108,6 +149,8 @@ def cpu_baseline(plan, budget_s=60.0, full=True):
     opt = torch.optim.SGD(model.parameters(), lr=3e-4, momentum=0.9, nesterov=True)
     model.train()
 
+    seen = {}
+
     def step(bin_):
         wavs, labels, lens = bin_
         t0 = time.time()
@@ -118,9 +161,11 @@ def cpu_baseline(plan, budget_s=60.0, full=True):
                           torch.from_numpy(lens).long(), blank=0, reduction='sum') / len(wavs)
         opt.zero_grad()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 400)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 400)
         opt.step()
-        return time.time() - t0
+        dt = time.time() - t0
+        seen.update(logits=logits.detach().numpy(), loss_sum=float(loss.item()) * len(wavs), gnorm=float(gn))
+        return dt
 
     order = sorted(range(len(plan)), key=lambda i: frames_of_plan(plan[i]))
     picks = [order[int(round(q * (len(order) - 1)))] for q in (0.0, 0.25, 0.5, 0.75, 1.0)]
@@ -128,9 +173,49 @@ def cpu_baseline(plan, budget_s=60.0, full=True):
     for _ in range(2):
         step(warm)
     rates, used, spent = [], [], 0.0
+    parity_out = None
+    # the parity leg's bin (the longest) goes FIRST among the timed steps, so that --cpu-quick cannot skip it
+    if parity is not None:
+        want = [i for i in picks if plan[i] is parity['plan_entry'] or plan[i][0] == parity['plan_entry'][0]]
+        picks = want + [i for i in picks if i not in want]
     for idx in picks:
         b = make_bin(plan[idx])
+        check = parity is not None and plan[idx][0] == parity['plan_entry'][0]
+        if check:
+            # the SAME weights and BatchNorm buffers as the HIP model had for this bin (the oracle's momentum buffers do not
+            # enter the forward pass, the loss or the gradient); eval-mode decode first (outside the timed step), then the
+            # timed training step, whose logits / loss / gradient norm are what the HIP step is compared with
+            from oracle import host as ohost
+            model.load_state_dict(parity['state_dict'])
+            model.eval()
+            with torch.no_grad():
+                xe, pe = ospec.batch_log_spectrogram(b[0])
+                probs = model(torch.from_numpy(xe)).numpy()
+            model.train()
+            sizes = (torch.from_numpy(pe) * probs.shape[1]).int().numpy()
+            cpu_strings, _ = ohost.greedy_decode(probs, sizes, parity['labels_txt'])
         dt = step(b)
+        if check:
+            gl, cl = parity['logits'], seen['logits']
+            valid = np.arange(cl.shape[1])[None, :] < sizes[:, None]          # frames inside each utterance's out_size
+            diff = np.abs(gl - cl).max(-1)
+            parity_out = {
+                'bin': '%d clips of %.1f-%.1f s, T_in = %d' % (len(b[0]), float(plan[idx][1].min()), float(plan[idx][1].max()),
+                                                                xe.shape[1]),
+                't_out': int(cl.shape[1]),
+                'logits_max_abs_err': float(diff[valid].max()),
+                'logits_max_abs_err_incl_padding_frames': float(diff.max()),
+                'loss_rel_err': abs(parity['loss_sum'] - seen['loss_sum']) / abs(seen['loss_sum']),
+                'loss_sum_hip': parity['loss_sum'], 'loss_sum_cpu_oracle': seen['loss_sum'],
+                'grad_norm_rel_err': abs(parity['gnorm'] - seen['gnorm']) / seen['gnorm'],
+                'greedy_strings_equal': bool(parity['strings'] == list(cpu_strings)),
+                'greedy_strings_differing': int(sum(a != c for a, c in zip(parity['strings'], cpu_strings))),
+                'out_sizes_equal': bool(np.array_equal(parity['out_sizes'], sizes)),
+                'tolerances': 'north_star: logits 1e-3 abs, CTC loss 1e-4 rel, greedy strings identical',
+                'what': 'HIP path (STFT frontend -> model -> CTC -> backward) against the CPU oracle (oracle/: numpy STFT, '
+                        'torch CPU conv/BN/GRU/Linear, F.ctc_loss) on the SAME audio from the SAME weights: the HIP model\'s '
+                        'state_dict after this run\'s training steps is loaded into the oracle before its step on this bin'}
+            note('parity vs cpu oracle: %s' % json.dumps({k: v for k, v in parity_out.items() if k not in ('what', 'tolerances')}))
         note('cpu baseline: bin of %d frames in %.1f s' % (frames_of(b), dt))
         rates.append(frames_of(b) / dt)
         used.append('%.1f s clips: %d frames in %.1f s' % (float(np.mean(plan[idx][1])), frames_of(b), dt))
@@ -152,6 +237,8 @@ def cpu_baseline(plan, budget_s=60.0, full=True):
         b = (wavs, rng.integers(1, 29, size=int(lens.sum())).astype(np.int32), lens)
         dt = step(b)
         out['config3_8x15s'] = {'value': round(frames_of(b) / dt, 1), 'unit': 'frames/s', 'seconds': round(dt, 1)}
+    if parity_out is not None:
+        out['parity_vs_cpu_oracle'] = parity_out
     return out
 
 
@@ -186,6 +273,82 @@ def gru_pass_roofline(model, bsz, t):
         dur = float(np.median(res[name]))
         out[name] = (flop / dur / 1e12, dur, flop)
     return out
+
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak; 6 bf16 products per fp32-equivalent one
+
+
+def gemm_roofline(model, rows):
+    """Live HIP-event timing of the model's GEMM shapes at the mean bin (rows = T * B): the input projection (NT), the dX
+    GEMM (NN), dW_ih (TN) and the grouped dW_hh launch are the GEMM work of a layer.  fp32-equivalent TFLOP/s against the
+    bf16 pipe's dense peak / 6 partial products (the default split-operand family; DS2_GEMM_SPLIT=0: the fp32 pipe)."""
+    from ds2hip import ops
+    hid = model._rnn_hidden_size
+    dev = model._flat_p.device
+    r = model.rnns[1].rnn
+    w_ih = model._pair(r.weight_ih_l0, r.weight_ih_l0_reverse)
+    x = 0.5 * torch.randn(rows, hid, device=dev)
+    dg = 0.1 * torch.randn(rows, 6 * hid, device=dev)
+    dw = torch.zeros(6 * hid, hid, device=dev)
+
+    def timed(fn, reps=6):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    flop = 2.0 * rows * 6 * hid * hid
+    shapes = {
+        'input_projection_NT_%dx%dx%d' % (rows, 6 * hid, hid): timed(lambda: ops.gemm(x, w_ih, trans_b=True)),
+        'dX_NN_%dx%dx%d' % (rows, hid, 6 * hid): timed(lambda: ops.gemm(dg, w_ih, split_k=0)),
+        'dW_ih_TN_%dx%dx%d' % (6 * hid, hid, rows): timed(lambda: ops.gemm(dg, x, trans_a=True, out=dw, split_k=0)),
+    }
+    mode = ops.gemm_split_mode()
+    peak = PEAK_BF16_MFMA_TFLOPS / mode if mode else PEAK_F32_MFMA_TFLOPS
+    out = {'bound': 'mfma', 'unit': 'TFLOP/s (fp32-equivalent)', 'peak': round(peak, 1),
+           'peak_note': ('dense bf16 MFMA peak 2500 / %d partial products per fp32-equivalent product' % mode) if mode
+                        else 'fp32-input MFMA dense peak', 'shapes': {}}
+    for k, dur in shapes.items():
+        out['shapes'][k] = {'us': round(dur * 1e6, 1), 'achieved': round(flop / dur / 1e12, 1),
+                            'frac': round(flop / dur / 1e12 / peak, 4)}
+    first = next(iter(out['shapes'].values()))
+    out.update(kernel='gemm_bf16x_kernel (input projection of a BiGRU layer)' if mode else 'gemm_f32_kernel',
+               achieved=first['achieved'], frac=first['frac'])
+    return out
+
+
+def chain_time_share(model, trainer, front, resident_bin):
+    """ONE training step on one bin with a timing event at every phase boundary of the main stream (model._tick): the live
+    counterpart of profiles/*_kernel_stats.csv.  Times are CHAIN times -- what the main stream spends between two
+    boundaries, side-stream work that runs beside it not counted, waits for it counted."""
+    flat, offs, labels, lens = resident_bin
+    trainer.flush()
+    for _ in range(2):
+        inputs, pct = front(flat, offs)
+        trainer.update((inputs, labels, pct, lens), defer=False)
+    torch.cuda.synchronize()
+    model._ticks = []
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    inputs, pct = front(flat, offs)
+    trainer.update((inputs, labels, pct, lens), defer=False)
+    torch.cuda.synchronize()
+    ticks, model._ticks = model._ticks, None
+    share, prev = {}, e0
+    for name, ev in ticks:
+        if name == 'start':
+            name = 'frontend: STFT + log + normalise'
+        share[name] = share.get(name, 0.0) + prev.elapsed_time(ev)
+        prev = ev
+    total = sum(share.values())
+    return {'total_ms': round(total, 3), 'T_in': int(inputs.shape[1]), 'B': int(inputs.shape[0]),
+            'phases_ms': {k: round(v, 3) for k, v in share.items()},
+            'phases_share': {k: round(v / total, 4) for k, v in share.items()}}
 
 
 _T0 = time.time()
@@ -251,13 +414,13 @@ def secondary_shape(trainer, front, dev, bsz, bins_durations, steps=None, warmup
     def step(i):
         flat, offs, labels, lens = res[i % len(res)]
         inputs, pct = front(flat, offs)
-        return trainer.update((inputs, labels, pct, lens), defer=True)
+        return trainer.update((inputs, labels, pct, lens), defer=False)        # the headline's protocol: a sync per step
 
     dt, per, _ = timed_steps(step, steps, warmup, False)
     idxs = [i % len(bins) for i in range(warmup, warmup + steps)]
     fr = float(sum(frames_of(bins[i]) for i in idxs))
-    osteps = float(sum(out_steps_of(bins[i]) for i in idxs))
-    tf = osteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12
+    vsteps = float(sum(valid_out_steps_of(bins[i]) for i in idxs))
+    tf = vsteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12
     return {'frames_per_s': round(fr / dt, 1), 'ms_per_step': round(1e3 * dt / steps, 2),
             'whole_step_tflops': round(tf, 2), 'whole_step_frac_of_f32_mfma_peak': round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
 
@@ -305,19 +468,23 @@ def loader_leg(trainer, plan, dev, workers=4):
         # two passes feeding the training step, each over all the bins in a fresh shuffled order
         for epoch, name in enumerate(('warmup', 'loader_and_frontend_only', 'train', 'train')):
             sampler.shuffle(epoch + 1)
-            frames = 0
+            frames = padded = 0
             torch.cuda.synchronize()
             t0 = time.time()
             for inputs, targets, pct, sizes in loader:
                 frames += int(round(float(pct.sum()) * inputs.shape[1]))
+                padded += int(inputs.shape[0] * inputs.shape[1])           # what the step computes: B x T_max
                 if name == 'train':
                     trainer.update((inputs, targets, pct, sizes), defer=True)
             trainer.flush()
             torch.cuda.synchronize()
-            rate = round(frames / (time.time() - t0), 1)
-            note('loader leg pass %d (%s): %s frames/s' % (epoch, name, rate))
-            if name != 'warmup':
-                out[name + '_frames_per_s'] = max(rate, out.get(name + '_frames_per_s', 0.0))
+            el = time.time() - t0
+            rate = round(frames / el, 1)
+            note('loader leg pass %d (%s): %s frames/s (%s padded)' % (epoch, name, rate, round(padded / el, 1)))
+            if name != 'warmup' and rate > out.get(name + '_frames_per_s', 0.0):
+                out[name + '_frames_per_s'] = rate
+                out[name + '_padded_frames_per_s'] = round(padded / el, 1)      # the drawn tempo (0.85-1.15) un-sorts a bin
+                out[name + '_padding_overhead'] = round(padded / max(frames, 1) - 1.0, 4)
         del loader
         return out
     finally:
@@ -389,40 +556,43 @@ def main():
     trainer = Trainer(model, opt, device=dev, max_norm=400)
     front = BatchSpectrogram(device=dev)
 
-    def step(i):
+    # THE HEADLINE is SURVEY.md 8(d)'s literal protocol: the host synchronises at the end of EVERY step, as the reference's
+    # codes/engine.py:92 does (round 3 reported the deferred-readback rate as the headline and this one beside it).
+    def step_sync(i):
+        flat, offs, labels, lens = resident[i % len(resident)]
+        inputs, pct = front(flat, offs)
+        return trainer.update((inputs, labels, pct, lens), defer=False)
+
+    def step(i):       # the product's training loop (Trainer.run / train.py): the step's one readback deferred by one step
         flat, offs, labels, lens = resident[i % len(resident)]
         inputs, pct = front(flat, offs)
         return trainer.update((inputs, labels, pct, lens), defer=True)
 
     trainer.reserve(int(float(os.environ.get('DS2_BENCH_RESERVE_GB', '4')) * (1 << 30)))   # one allocator block up front
     note('model built, inputs resident; timing')
-    dt, per, loss = timed_steps(step, args.steps, args.warmup, use_dist)
-    note('timed region done: %.2f ms/step' % (1e3 * dt / args.steps))
+    dt, per, loss = timed_steps(step_sync, args.steps, args.warmup, use_dist)
+    note('timed region done (a host synchronisation in every step): %.2f ms/step' % (1e3 * dt / args.steps))
     idxs = [i % len(mine) for i in range(args.warmup, args.warmup + args.steps)]
     frames = float(sum(frames_of(mine[i]) for i in idxs))
     osteps = float(sum(out_steps_of(mine[i]) for i in idxs))
+    vsteps = float(sum(valid_out_steps_of(mine[i]) for i in idxs))
+    pframes = float(sum(max(1 + len(w) // HOP for w in mine[i][0]) * len(mine[i][0]) for i in idxs))
     step_rates = sorted(frames_of(mine[i]) / t for i, t in zip(idxs, per))      # this rank's per-step frames/s
     per_sorted = sorted(per)
     if use_dist:
-        t = torch.tensor([dt, frames, osteps], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, frames, osteps, vsteps, pframes], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, frames, osteps = float(tmax[0]), float(t[1]), float(t[2])
+        dt, frames, osteps, vsteps, pframes = float(tmax[0]), float(t[1]), float(t[2]), float(t[3]), float(t[4])
 
-    # the same steps with the reference's host synchronisation in EVERY step (codes/engine.py:92) instead of the readback
-    # deferred by one step: SURVEY.md 8(d)'s literal protocol, reported beside the headline
-    def step_sync(i):
-        flat, offs, labels, lens = resident[i % len(resident)]
-        inputs, pct = front(flat, offs)
-        return trainer.update((inputs, labels, pct, lens), defer=False)
-
-    dt_sync, _, _ = timed_steps(lambda i: step_sync(i + args.warmup), args.steps, 0, use_dist)
+    # the same steps as the product's own loop runs them: each step's readback deferred by one step
+    dt_defer, _, _ = timed_steps(lambda i: step(i + args.warmup), args.steps, 0, use_dist)
     if use_dist:
-        ts = torch.tensor([dt_sync], dtype=torch.float64, device=dev)
+        ts = torch.tensor([dt_defer], dtype=torch.float64, device=dev)
         dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        dt_sync = float(ts[0])
-    note('sync-per-step leg done: %.2f ms/step' % (1e3 * dt_sync / args.steps))
+        dt_defer = float(ts[0])
+    note('deferred-readback leg done: %.2f ms/step' % (1e3 * dt_defer / args.steps))
 
     # the same steps with every GEMM, conv2's forward pass and (B >= 17) the forward recurrence on the f32-input MFMA kernels
     # (ds2_gemm_split_mode 0, DS2_CONV_SPLIT=0, DS2_GRU_P2_BF16=0) instead of the default split-operand kernels on the bf16
@@ -532,16 +702,27 @@ def main():
             torch.cuda.synchronize()
             inf_dt = time.time() - ti
     model.train()
-    step_tflops = osteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12 / world    # per GPU, padded steps included
+    step_tflops = vsteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12 / world           # per GPU, from the utterances' OWN steps
+    step_tflops_padded = osteps * TRAIN_FLOP_PER_OUT_STEP / dt / 1e12 / world    # what was computed (bins padded to the longest)
     t_mean = int(round(np.mean([out_steps_of(b) / len(b[0]) for b in mine])))
     note('inference leg done')
     roof = gru_pass_roofline(model, bsz, t_mean)
-    note('roofline leg done')
+    gemm_roof = gemm_roofline(model, t_mean * bsz)
+    note('roofline legs done')
+    mean_bin = min(range(len(mine)), key=lambda i: abs(out_steps_of(mine[i]) / len(mine[i][0]) - t_mean))
+    share = chain_time_share(model, trainer, front, resident[mean_bin])
+    note('chain time share: %s' % json.dumps(share['phases_ms']))
+    parity = None
+    if not args.no_cpu_baseline and world == 1 and args.fixed_seconds <= 0:
+        longest = max(range(len(plan)), key=lambda i: frames_of_plan(plan[i]))
+        parity = gpu_parity_side(model, trainer, front, decoder, plan[longest], dev)
+        parity['labels_txt'] = ['_', ' ', "'"] + [chr(65 + i) for i in range(26)]
+        note('parity leg (HIP side) done: loss_sum %.4f' % parity['loss_sum'])
     ach, dur, flop = roof['bwd']
     # HBM-side bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of the same shape whose
     # summary is committed under profiles/ (PMC collection cannot run inside this process); the file is named below
     traffic, traffic_src = None, None
-    for name in ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
+    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
@@ -563,10 +744,16 @@ def main():
                                   else 'all %.1f s long' % args.fixed_seconds),
                    'batch_per_gpu': bsz, 'global_batch': bsz * world, 'parallelism': 'dp%d' % world,
                    'last_loss': round(float(loss), 4),
-                   'sync_per_step': {'frames_per_s': round(frames / dt_sync, 1),
-                                     'ms_per_step': round(1e3 * dt_sync / args.steps, 3),
-                                     'note': 'the same steps with a host synchronisation in every step (codes/engine.py:92); '
-                                             'the headline defers each step\'s one readback by one step'},
+                   'protocol': 'value / ms_per_step: a host synchronisation at the end of EVERY step (codes/engine.py:92, SURVEY.md '
+                               '8d); frames = valid spectrogram frames 1 + L // 160 of every clip (padding not counted)',
+                   'padded_frames_per_s': round(pframes / dt, 1),
+                   'padding_note': 'a bin is padded to its longest clip (codes/data.py:132-152): B x T_max frames are computed per '
+                                   'step, the valid ones are counted',
+                   'deferred_readback': {'frames_per_s': round(frames / dt_defer, 1),
+                                         'ms_per_step': round(1e3 * dt_defer / args.steps, 3),
+                                         'note': 'the same steps as Trainer.run / train.py run them: each step\'s one readback '
+                                                 'deferred by one step (round 3\'s headline)'},
+                   'chain_time_share': share,
                    'gemm_arithmetic': {
                        'mode': gemm_mode,
                        'note': ('fp32 operands, fp32 accumulator, fp32 result; products on the bf16 matrix pipe after an '
@@ -577,7 +764,8 @@ def main():
                                if gemm_mode else 'f32-input MFMA kernels (v_mfma_f32_32x32x2_f32)',
                        'kernels_on_the_bf16_pipe': 'GEMMs, conv2 forward, forward recurrence from B = 17',
                        'same_steps_on_f32_input_mfma_gemms': None if dt_f32 is None else {
-                           'frames_per_s': round(frames / dt_f32, 1), 'ms_per_step': round(1e3 * dt_f32 / args.steps, 3)}},
+                           'frames_per_s': round(frames / dt_f32, 1), 'ms_per_step': round(1e3 * dt_f32 / args.steps, 3),
+                           'note': 'deferred readback: compare with config.deferred_readback'}},
                    'persistent_to_step_fallbacks': (_fallbacks() if ddp is None
                                                     else ddp['persistent_to_step_fallbacks']),
                    'ms_per_step_rank0': {'median': round(1e3 * pct_of(per_sorted, 0.5), 3),
@@ -587,17 +775,33 @@ def main():
                                                    'p10': round(pct_of(step_rates, 0.1), 1),
                                                    'p90': round(pct_of(step_rates, 0.9), 1)},
                    'inference_frames_per_s_rank0': round(inf_frames / inf_dt, 1)},
-        'roofline': {'bound': 'mfma',
+        'roofline': {'bound': 'latency' if bsz <= 16 else 'mfma',
+                     'bound_note': 'one launch = T dependent time steps; a step is a chain of three phases on every CU -- the '
+                                   'inter-CU hand-off of the new state through memory, the matrix phase at the fp32 MFMA rate '
+                                   'of the CUs it occupies, and the gate / reduction skeleton (DESIGN.md section 6).  achieved / '
+                                   'peak / frac price the launch against the fp32-input MFMA roof (the contract\'s yardstick); '
+                                   'floor_us_per_step is what the latency model allows',
                      'kernel': 'gru_bwd_persistent4_kernel (one launch = all T=%d steps of a BiGRU layer, both '
                                'directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                      'avg_launch_us': round(dur * 1e6, 1), 'us_per_time_step': round(dur * 1e6 / t_mean, 3),
+                     'floor_us_per_step': {
+                         'handoff_all_to_all': 1.3, 'matrix_phase_bwd': 1.06, 'matrix_phase_fwd': 0.73, 'sum_bwd': 2.36,
+                         'sum_fwd': 2.03,
+                         'note': 'measured floors at B = 10, H = 800: a two-operation (store, load) all-to-all hand-off across '
+                                 'XCDs costs 1.3-1.5 us (tools/spec_handoff_probe.hip); the matrix phase is 288 (bwd, 24 units '
+                                 'per CU) resp. 200 (fwd, 20 units, k dealt evenly) v_mfma_f32_4x4x1 per SIMD at 8.8 cycles / '
+                                 '2.4 GHz; the gate / reduction skeleton (0.4 us on the chain today) has no hardware floor'},
                      'flop_per_launch': flop,
                      'fwd_kernel_tflops': round(roof['fwd'][0], 3),
                      'fwd_us_per_time_step': round(roof['fwd'][1] * 1e6 / t_mean, 3),
                      'whole_step_tflops_per_gpu': round(step_tflops, 3),
-                     'whole_step_frac_of_f32_mfma_peak': round(step_tflops / PEAK_F32_MFMA_TFLOPS, 5)},
+                     'whole_step_frac_of_f32_mfma_peak': round(step_tflops / PEAK_F32_MFMA_TFLOPS, 5),
+                     'whole_step_tflops_per_gpu_padded': round(step_tflops_padded, 3),
+                     'whole_step_note': 'FLOP = 261.94 M x the utterances\' own output steps (valid frames); _padded counts the '
+                                        'steps computed (every clip padded to its bin\'s longest)',
+                     'gemm': gemm_roof},
     }
     if cfg3 is not None:
         result['config']['config3'] = cfg3
@@ -615,7 +819,9 @@ def main():
         result['config']['loader'] = loader_leg(trainer, plan, dev)
         note('loader leg done')
     if not args.no_cpu_baseline and world == 1:      # the CPU oracle is timed beside the GPU at N = 1 only
-        result['cpu_baseline'] = cpu_baseline(plan, budget_s=args.cpu_budget_s, full=not args.cpu_quick)
+        result['cpu_baseline'] = cpu_baseline(plan, budget_s=args.cpu_budget_s, full=not args.cpu_quick, parity=parity)
+        if 'parity_vs_cpu_oracle' in result['cpu_baseline']:
+            result['parity_vs_cpu_oracle'] = result['cpu_baseline'].pop('parity_vs_cpu_oracle')
     if use_dist:
         dist.destroy_process_group()
     sys.stdout.flush()

@@ -35,6 +35,11 @@ extern "C" {
 #define DS2_ERR_UNSUPPORTED (-3)
 
 const char* ds2_last_error(void);
+/* The ABI revision this header describes.  ds2_version() of the loaded library must return exactly this number: signatures
+ * have changed between revisions without a change of symbol name (round 3: an amplitude-scale argument in
+ * ds2_pcm16_to_float / ds2_gain_requantize; round 4: ds2_conv2_dgrad takes the size of its workspace), so a binding built
+ * against another revision mis-passes arguments.  ds2hip/lib.py refuses to load a library whose number differs. */
+#define DS2_ABI_VERSION 400
 int ds2_version(void);
 
 /* ------------------------------------------------------------------ frontend
@@ -120,8 +125,10 @@ int ds2_gemm_f32_tn_group(int count, const float* const* A_host, const int* lda_
  *          kernel (32,1,41,11), stride (2,2), padding (0,10)
  *   conv2: a1 (B,32,61,T1) -> y (B,32,21,T); kernel (32,32,21,11), stride (2,1), no padding
  * which = 1 or 2.  Weights are passed in the torch layout (Cout,Cin,KF,KT) plus bias (32).
- * wt_ws: workspace of ds2_conv_wt_ws_floats(which) floats for the re-laid-out filter (ds2_conv2_dgrad: of
- * ds2_conv2_dgrad_ws_floats(B, T1) floats -- its default form also keeps a zero-bordered copy of d_out there).
+ * wt_ws: workspace of ds2_conv_wt_ws_floats(which) floats for the re-laid-out filter.  ds2_conv2_dgrad takes its workspace
+ * WITH its size: ds2_conv2_dgrad_ws_floats(B, T1) floats let it choose its gather form, which keeps a zero-bordered copy of
+ * d_out there (several million floats); with fewer -- but at least ds2_conv_wt_ws_floats(2) -- it runs the direct kernel;
+ * with fewer than that it returns DS2_ERR_ARG.  It never writes past ws_floats.
  * Arithmetic of conv2's forward pass and data gradient: fp32 operands, accumulator and result; by default the products run
  * on the bf16 matrix pipe after the error-free three-way operand split described at ds2_gemm_f32 (six exact partial
  * products; DS2_CONV_SPLIT=9 all nine, =0 the direct kernels on the f32-input matrix instruction; the data gradient takes
@@ -134,7 +141,7 @@ int ds2_conv_fwd(int which, const float* in, const float* weight, const float* b
 /* dgrad (conv2 only): d_in (B,32,61,T1) from d_out (B,32,21,T) */
 size_t ds2_conv2_dgrad_ws_floats(int B, int T1);
 int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, int T1, float* d_in, float* wt_ws,
-                    void* stream);
+                    size_t ws_floats, void* stream);
 /* wgrad: d_weight (Cout,Cin,KF,KT) and d_bias (32) OVERWRITTEN (d_weight zeroed inside) */
 int ds2_conv_wgrad(int which, const float* in, const float* d_out, int B, int t_in_frames, float* d_weight,
                    float* d_bias, void* stream);

@@ -24,6 +24,20 @@ path, loads the portable weights-from-seed recipe (oracle/model.py
                  en layer copied through data/map_en-pt_BR.json, the other rows from the
                  seeded recipe -- then one forward/backward of the reference model.
 
+  ref_full_b10_15s / ref_full_b32_10s.npz   (round 4)
+                 the lengths the headline metric is quoted on: B=10 with the longest clip 15 s (T_in = 1501 -> T = 746
+                 output steps) and B=32 at 10 s (T_in = 1001 -> T = 496; the two-part recurrence forms with bf16 state
+                 planes over a long chain), ragged.  ``lnoise`` / ``pnoise`` = how far the reference's own fp32 logits /
+                 probabilities are from its float64 twin's.
+  ref_sharp_b10.npz
+                 the same model with every weight matrix drawn 3x wider (``seeded_state_dict(scale=3.0)``): confident
+                 outputs, a recurrence that is much less contractive, T_in = 801.
+  ref_traj_b10.npz
+                 FIVE optimisation steps of the reference model as ``codes/engine.py:45-94`` runs them (loss / B,
+                 ``clip_grad_norm_(400)``, SGD lr 3e-4 momentum 0.9 Nesterov -- scripts/librispeech-from_scratch.json) on
+                 two alternating B=10 minibatches: per-step loss and gradient norm, the final BatchNorm buffers, strided
+                 samples of the final weights and of the momentum buffers.
+
 The GPU box regenerates weights and inputs from the same seeds, so only outputs
 are stored.  Nothing here is read at test time except the .npz files.
 """
@@ -78,10 +92,12 @@ def label_lengths_for(lengths, per_frame=0.09):
 
 
 def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads, tstride=1, finetune43=False,
-             f64_truth=False):
+             f64_truth=False, weight_scale=None, trajectory=0, lnoise=False):
+    if trajectory:
+        return run_trajectory(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, trajectory)
     torch.manual_seed(0)
     model = ref.DeepSpeech(**model_kwargs)
-    sd = seeded_state_dict(model, seed=1234)
+    sd = seeded_state_dict(model, seed=1234, scale=weight_scale)
     model.load_state_dict(sd)
     nalpha = model_kwargs.get('num_classes', 29)
     if finetune43:
@@ -155,11 +171,19 @@ def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads
             flat = p.grad.numpy().reshape(-1)
             stride = max(1, flat.shape[0] // 1024)
             out['gnoise_' + k] = np.float32(np.abs(flat[::stride][:1024] - out['gsample_' + k]).max())
+        if lnoise:
+            out['lnoise'] = np.float32(np.abs(logits64.detach().numpy() - logits.detach().numpy()).max())
+            out['loss64'] = np.float64(loss64.item())
+            model64.eval()
+            with torch.no_grad():
+                probs64 = model64(x.double()).numpy()
 
     model.eval()
     with torch.no_grad():
         probs = model(x)
     out['probs'] = probs.numpy()[:, ::tstride].copy()
+    if f64_truth and lnoise:
+        out['pnoise'] = np.float32(np.abs(probs64 - probs.numpy()).max())
     if tstride > 1:
         # every frame: best and runner-up class plus whether they are closer than 1e-4 (with near-uniform outputs of
         # random weights some frames are ties at fp32 round-off; there the runner-up is an equally valid argmax)
@@ -171,6 +195,63 @@ def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads
     np.savez_compressed(os.path.join(HERE, name), **out)
     print(name, 'logits', out['logits'].shape, 'loss', out['loss_sum'],
           'size %.1f KB' % (os.path.getsize(os.path.join(HERE, name)) / 1024.0))
+
+
+def traj_batches(bsz, t_in, lengths, label_lens, nalpha=29):
+    """The two minibatches the trajectory alternates between (the second: other values, the lengths reversed in time order
+    of the draw so that the BatchNorm statistics differ)."""
+    a = (seeded_inputs(77, bsz, t_in, lengths=lengths), seeded_labels(78, label_lens, nalpha))
+    b = (seeded_inputs(79, bsz, t_in, lengths=lengths), seeded_labels(80, label_lens, nalpha))
+    return [a, b]
+
+
+TRAJ_OPT = dict(lr=3e-4, momentum=0.9, nesterov=True)      # scripts/librispeech-from_scratch.json
+TRAJ_MAX_NORM = 400.0
+
+
+def run_trajectory(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, steps):
+    """``steps`` updates of the reference model exactly as codes/engine.py:45-94 does them (warp-ctc's place taken by
+    F.ctc_loss on log_softmax, reduction sum -- SURVEY 8c)."""
+    torch.manual_seed(0)
+    model = ref.DeepSpeech(**model_kwargs)
+    model.load_state_dict(seeded_state_dict(model, seed=1234))
+    opt = torch.optim.SGD(model.parameters(), **TRAJ_OPT)
+    batches = traj_batches(bsz, t_in, lengths, label_lens)
+    pct = torch.tensor([n / float(t_in) for n in lengths], dtype=torch.float32)
+    out = {'pct': pct.numpy(), 'losses': [], 'gnorms': []}
+    for i in range(steps):
+        x, labels = batches[i % 2]
+        model.train()
+        logits = model(torch.from_numpy(x))
+        out_sizes = (pct * logits.shape[1]).int()
+        loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), torch.from_numpy(labels).long(), out_sizes.long(),
+                          torch.tensor(label_lens, dtype=torch.long), blank=0, reduction='sum') / bsz
+        opt.zero_grad()
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), TRAJ_MAX_NORM)
+        opt.step()
+        out['losses'].append(loss.item())
+        out['gnorms'].append(float(gn))
+        print('  step', i, 'loss', loss.item(), 'gnorm', float(gn))
+    out['losses'] = np.asarray(out['losses'], np.float64)
+    out['gnorms'] = np.asarray(out['gnorms'], np.float64)
+    out['out_sizes'] = out_sizes.numpy().astype(np.int32)
+    for k, p in model.named_parameters():
+        flat = p.detach().numpy().reshape(-1)
+        stride = max(1, flat.shape[0] // 1024)
+        out['wsample_' + k] = flat[::stride][:1024].copy()
+        out['wnorm_' + k] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        mom = opt.state[p]['momentum_buffer'].numpy().reshape(-1)
+        out['msample_' + k] = mom[::stride][:1024].copy()
+    for k, v in model.state_dict().items():
+        if 'running' in k:
+            out['buf_' + k] = v.numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        probs = model(torch.from_numpy(batches[0][0])).numpy()
+    out['probs'] = probs[:, ::2].copy()
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, 'losses', out['losses'], 'size %.1f KB' % (os.path.getsize(os.path.join(HERE, name)) / 1024.0))
 
 
 def cases():
@@ -189,6 +270,24 @@ def cases():
                                    f64_truth=True)
 
 
+    # round 4: the lengths the metric is quoted on, a sharp-weight model, and a 5-step trajectory
+    lens = ragged_lengths(1510, 10, 1501)
+    yield 'ref_full_b10_15s.npz', dict(model_kwargs=dict(), bsz=10, t_in=1501, lengths=lens,
+                                       label_lens=label_lengths_for(lens), full_grads=False, tstride=8, f64_truth=True,
+                                       lnoise=True)
+    lens = ragged_lengths(1032, 32, 1001)
+    yield 'ref_full_b32_10s.npz', dict(model_kwargs=dict(), bsz=32, t_in=1001, lengths=lens,
+                                       label_lens=label_lengths_for(lens), full_grads=False, tstride=16, f64_truth=True,
+                                       lnoise=True)
+    lens = ragged_lengths(810, 10, 801)
+    yield 'ref_sharp_b10.npz', dict(model_kwargs=dict(), bsz=10, t_in=801, lengths=lens,
+                                    label_lens=label_lengths_for(lens), full_grads=False, tstride=4, f64_truth=True,
+                                    weight_scale=3.0, lnoise=True)
+    lens = ragged_lengths(510, 10, 301)
+    yield 'ref_traj_b10.npz', dict(model_kwargs=dict(), bsz=10, t_in=301, lengths=lens,
+                                   label_lens=label_lengths_for(lens), full_grads=False, trajectory=5)
+
+
 CASES = dict(cases())
 
 
@@ -200,6 +299,10 @@ def expected_keys(name):
     kw = CASES[name]
     model = OracleDeepSpeech(**kw['model_kwargs'])
     params = [k for k, _ in model.named_parameters()]
+    if kw.get('trajectory'):
+        keys = {'pct', 'losses', 'gnorms', 'out_sizes', 'probs'}
+        keys |= {pre + k for k in params for pre in ('wsample_', 'wnorm_', 'msample_')}
+        return keys | {'buf_' + k for k in model.state_dict() if 'running' in k}
     keys = {'logits', 'tstride', 'loss_sum', 'out_sizes', 'pct', 'probs'}
     keys |= {'gnorm_' + k for k in params}
     keys |= {('grad_' if kw['full_grads'] else 'gsample_') + k for k in params}
@@ -208,6 +311,8 @@ def expected_keys(name):
         keys |= {'inter_conv1', 'inter_conv2'} | {'inter_rnn%d' % i for i in range(kw['model_kwargs'].get('num_rnn_layers', 5))}
     if kw.get('f64_truth'):
         keys |= {'gnoise_' + k for k in params}
+        if kw.get('lnoise'):
+            keys |= {'lnoise', 'pnoise', 'loss64'}
     if kw.get('tstride', 1) > 1:
         keys |= {'argmax', 'argmax2', 'near_tie'}
     return keys

@@ -36,8 +36,10 @@ def check_against_golden(g, logits, loss_sum, grads, buffers, probs, logit_tol, 
         gn = float(np.sqrt((gr.astype(np.float64) ** 2).sum()))
         ref_gn = float(g['gnorm_' + k])
         if k in ('conv.0.bias', 'conv.3.bias'):
-            # a bias in front of a BatchNorm has an exactly-zero gradient; both sides hold only round-off
-            assert gn < 1e-2 and ref_gn < 1e-2, k
+            # a bias in front of a BatchNorm has an exactly-zero gradient; both sides hold only round-off -- of sums whose
+            # terms scale with the layer's filter gradient (2e-5 of it in the reference's own fp32 run at 15 s)
+            scale = max(1.0, float(g['gnorm_' + k.replace('bias', 'weight')]) / 100.0)
+            assert gn < 1e-2 * scale and ref_gn < 1e-2 * scale, k
             continue
         assert abs(gn - ref_gn) <= gnorm_rtol * ref_gn + 1e-6, (k, gn, ref_gn)
         flat = gr.reshape(-1)

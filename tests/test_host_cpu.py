@@ -39,7 +39,11 @@ def test_library_exports_every_declared_symbol():
             if not is_ptr:
                 kind = {'int': ctypes.c_int, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t}[a.split()[0]]
                 assert ct is kind, (name, a)
-    assert lib.query('ds2_version') >= 100
+    # one ABI revision number in three places: the header, the binding, the binary (a stale binary mis-passes arguments)
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'ds2hip.h')).read()
+    assert int(re.search(r'#define\s+DS2_ABI_VERSION\s+(\d+)', hdr).group(1)) == lib.ABI_VERSION
+    assert lib.query('ds2_version') == lib.ABI_VERSION
     assert lib.query('ds2_bn_ws_bytes', 32) > 0
 
 

@@ -190,11 +190,13 @@ def _conv_ref(which, x, w, b):
 @pytest.mark.parametrize('which,bsz,t_in,wlds', [(1, 2, 121, '0'), (1, 3, 64, '0'), (2, 2, 66, '0'), (2, 1, 43, '0'),
                                                  (1, 1, 301, '0'), (2, 2, 66, '1'), (2, 3, 139, '1'), (2, 1, 43, '1'),
                                                  (2, 2, 66, 'dgrad-split'), (2, 3, 139, 'dgrad-split'), (2, 1, 43, 'dgrad-split'),
-                                                 (2, 4, 301, 'dgrad-split')])
+                                                 (2, 4, 301, 'dgrad-split'), (2, 1, 1060, 'dgrad-split')])
 def test_conv_fwd_bwd(ops, monkeypatch, which, bsz, t_in, wlds):
     """(wlds = '1': conv2's direct forward kernel in the filter-through-LDS form, which large batches select by themselves;
     'dgrad-split': the data gradient through the gather kernel on the bf16 matrix pipe, csrc/conv_split.hip, which the
-    forward pass uses by default.  The direct forward kernels are covered by test_conv2_forward_families_agree.)"""
+    forward pass uses by default.  The direct forward kernels are covered by test_conv2_forward_families_agree.
+    B = 1, t1 = 1060: the even-row launch (31 rows) has 1024+ waves and does not split K, the odd-row launch (30 rows) has
+    fewer and does -- the output's one zero fill must precede BOTH (round 3's second launch wiped the first one's rows).)"""
     if wlds == 'dgrad-split':
         monkeypatch.setenv('DS2_CONV_SPLIT_DGRAD', '1')
         wlds = '0'

@@ -78,7 +78,7 @@ def _oracle_case(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name))
     kw, x, labels, nalpha = case_inputs(name)
     model = OracleDeepSpeech()
-    model.load_state_dict(seeded_state_dict(model, 1234))
+    model.load_state_dict(seeded_state_dict(model, 1234, scale=kw.get('weight_scale')))
     if kw.get('finetune43'):
         head = model.fc[0].module
         new = torch.nn.Linear(800, 43, bias=False)
@@ -105,3 +105,9 @@ def test_full_model_b8_matches_reference(golden_dir):
 
 def test_finetuned_pt_br_head_matches_reference(golden_dir):
     _oracle_case(golden_dir, 'ref_ft43_b16.npz')
+
+
+def test_sharp_weight_model_matches_reference(golden_dir):
+    """3x wider weights (confident outputs, a much less contractive recurrence), T_in = 801: the oracle is the reference here
+    too -- bench.py's parity block and smoke() compare the HIP path with THIS model."""
+    _oracle_case(golden_dir, 'ref_sharp_b10.npz')
