@@ -1,7 +1,7 @@
 // Error reporting + version for libds2hip.so.
 #include <stdarg.h>
 
-#include "ds2_common.h"
+#include "ds2_host.h"
 
 static thread_local char g_err[512] = "";
 

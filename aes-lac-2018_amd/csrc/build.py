@@ -34,6 +34,27 @@ def _newer(src, dst, deps):
     return any(os.path.getmtime(p) > t for p in [src] + deps)
 
 
+HOST_SOURCES = ('api.hip', 'decode_host.hip')          # host-only translation units (no device code, no HIP header)
+
+
+def build_host_sanitized(out=None):
+    """TEST INFRASTRUCTURE, CPU only: the host-side C++ of the library (error string / version, Levenshtein distance, CTC
+    prefix beam search) compiled by g++ with AddressSanitizer + UndefinedBehaviorSanitizer into a stand-alone shared object
+    (default tests/libds2host_asan.so).  tests/test_host_asan_cpu.py loads it in a child python with libasan preloaded and
+    fuzzes it.  Never loaded by the product, never run on the GPU box's device (sanitizers are unavailable there)."""
+    out = out or os.path.join(ROOT, 'tests', 'libds2host_asan.so')
+    srcs = [os.path.join(HERE, f) for f in HOST_SOURCES]
+    if not _newer(srcs[0], out, srcs[1:] + [os.path.join(HERE, 'ds2_host.h'), os.path.join(ROOT, 'include', 'ds2hip.h')]):
+        return out
+    cmd = [os.environ.get('CXX', 'g++'), '-x', 'c++', '-std=c++17', '-O1', '-g', '-fno-omit-frame-pointer',
+           '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-shared', '-fPIC',
+           '-I', os.path.join(ROOT, 'include'), '-I', HERE] + srcs + ['-o', out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('sanitizer build failed: %s\n%s\n%s' % (' '.join(cmd), r.stdout, r.stderr))
+    return out
+
+
 def build_gemm_variant(name, flags):
     """libds2hip_<name>.so with gemm.hip recompiled with ``flags`` (tools/gemm_ablate.py)."""
     src = os.path.join(HERE, 'gemm.hip')

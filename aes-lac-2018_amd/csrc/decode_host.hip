@@ -11,7 +11,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "ds2_common.h"
+#include "ds2_host.h"
 
 extern "C" int ds2_edit_distance(const int32_t* a, int na, const int32_t* b, int nb) {
     DS2_CHECK_ARG(na >= 0 && nb >= 0 && (a || na == 0) && (b || nb == 0));

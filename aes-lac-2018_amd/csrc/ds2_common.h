@@ -4,14 +4,12 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#include "ds2hip.h"
+#include "ds2_host.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // float4 with only 4-byte alignment: lets hipcc emit one dwordx4 for an unaligned window
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-
-void ds2_set_error(const char* fmt, ...);
 
 // conv_split.hip (internal): conv2 on the bf16 matrix pipe; 0 = ran, 1 = not selected (the caller runs the direct kernels)
 size_t ds2_conv2_split_ws_floats();
@@ -19,14 +17,6 @@ size_t ds2_conv2_dgrad_split_ws_floats(int B, int t1);
 int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1, float* d_in, void* ws, hipStream_t st);
 int ds2_conv2_fwd_split(const float* in, const float* weight, const float* bias, int B, int t1, float* out, void* ws,
                         hipStream_t st);
-
-#define DS2_CHECK_ARG(cond)                                                        \
-    do {                                                                           \
-        if (!(cond)) {                                                             \
-            ds2_set_error("%s: bad argument: %s", __func__, #cond);                \
-            return DS2_ERR_ARG;                                                    \
-        }                                                                          \
-    } while (0)
 
 #define DS2_CHECK_LAUNCH()                                                         \
     do {                                                                           \

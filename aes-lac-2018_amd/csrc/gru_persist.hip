@@ -36,6 +36,17 @@ __device__ long long ds2_tbuf[32 * 8];
 extern "C" int ds2_debug_read_timing(long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ds2_tbuf), sizeof(long long) * 32 * 8) == hipSuccess ? 0 : -1;
 }
+// round 4: per-WAVE stamps of one workgroup ([step 100..131][wave 8][stamp 12], lane 0 of every wave), both 4x4x1 kernels
+// (the launch that ran last wins): tools/gru_wave_timing.py
+__device__ long long ds2_wbuf[32 * 8 * 12];
+#define DS2_WTICK(i)                                                                                      \
+    do {                                                                                                  \
+        if (lane == 0 && blockIdx.x == 5 && blockIdx.y == 0 && blockIdx.z == 0 && s >= 100 && s < 132)  \
+            ds2_wbuf[((s - 100) * 8 + wave) * 12 + (i)] = __builtin_amdgcn_s_memtime();                   \
+    } while (0)
+extern "C" int ds2_debug_read_wave_timing(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ds2_wbuf), sizeof(long long) * 32 * 8 * 12) == hipSuccess ? 0 : -1;
+}
 __device__ unsigned int ds2_retries;            // fragments re-loaded by the canary protocol (all kernels)
 extern "C" int ds2_debug_read_retries(unsigned int* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ds2_retries), sizeof(unsigned int)) != hipSuccess) return -1;
@@ -48,6 +59,7 @@ extern "C" int ds2_debug_read_retries(unsigned int* out, int reset) {
 #define DS2_RETRY_FLUSH(n) do { if ((threadIdx.x & 63) == 0 && (n)) __hip_atomic_fetch_add(&ds2_retries, (unsigned int)(n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
 #define DS2_TICK(i) do {} while (0)
+#define DS2_WTICK(i) do {} while (0)
 #define DS2_RETRY_FLUSH(n) do {} while (0)
 #endif
 
@@ -101,6 +113,16 @@ __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int 
 // hand-off payload load (a timing experiment with plain, L2-allocating loads showed no difference; a run-time
 // switch between the two forms here costs a branch and a vmcnt(0) join in front of the MFMAs)
 #define LOAD_HANDOFF(rs, off) load_sc1_b128(rs, off)
+// s_waitcnt vmcnt(0) as the BUILTIN (simm16: vmcnt = 0, expcnt and lgkmcnt at their maxima = not waited for), not as inline
+// asm: the compiler's wait-count insertion cannot see into an asm statement, so behind one it still believes the wave's
+// earlier loads are in flight -- and when a later instruction touches one of their destination registers (the loop-carried
+// saved-activation registers of the 4x4x1 kernels) it inserts a vmcnt(0) of its OWN at that point, which then also waits for
+// whatever was issued in between: round 4 found such a wait right behind the hand-off stores (0.4 us per step waiting for
+// the write-through acknowledgements before the next loads could issue), and, in the round-3 kernels, at the top of every step.
+__device__ __forceinline__ void wait_vmcnt0() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+}
 constexpr int OOB_OFFSET = 0x7FFFFFF0;    // beyond any descriptor's num_records: the range-checked load returns 0
 __device__ __forceinline__ void store_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -150,36 +172,68 @@ __device__ __forceinline__ bool has_canary(f32x4 v) {
     const u32x4 u = __builtin_bit_cast(u32x4, v);
     return (u[0] == CANARY_BITS) | (u[1] == CANARY_BITS) | (u[2] == CANARY_BITS) | (u[3] == CANARY_BITS);
 }
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N - 1 (the MFMA's ABID operand must be an immediate)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// canary test on the components MASK names (bit e = component e): the k-balanced deal's padding components are never written
+template <int MASK>
+__device__ __forceinline__ bool has_canary_masked(f32x4 v) {
+    const u32x4 u = __builtin_bit_cast(u32x4, v);
+    bool r = false;
+    if (MASK & 1) r |= u[0] == CANARY_BITS;
+    if (MASK & 2) r |= u[1] == CANARY_BITS;
+    if (MASK & 4) r |= u[2] == CANARY_BITS;
+    if (MASK & 8) r |= u[3] == CANARY_BITS;
+    return r;
+}
+
 
 // Speculative protocol: make sure no loaded fragment still holds the canary (returns true if one did).  Runs before the
 // MFMAs; stale fragments are re-loaded per load instruction (a wave-uniform decision) until clean, bounded by SPIN_TICKS like
 // every other spin.  Also adapts the wave's first-attempt delay: +1 after a step that needed a re-load, -1 after 4 clean steps.
-template <int NCI, int NGI, typename LoadFrag>
+// NVC > 0 (the k-balanced forward deal): only the first NVC components of a lane's NGI loads are ever written (component
+// c of load gi is number 4 gi + c); the others are padding nobody owns and must not be mistaken for a missing payload.
+// G0 .. G1 - 1: the loads this call checks (STAGED consumption, round 4: a k group's fragments are validated right before
+// its own MFMAs, so that the matrix work on the fragments that have landed runs under the wait for the rest -- the chip-wide
+// all-to-all delivers a step's hand-off loads over ~0.8 us, first issued first served: tools/gru_wave_timing.py); `acc`
+// carries "a re-load happened" from stage to stage and the delay adapts once, in the call with `last` set.
+template <int NCI, int NGI, int NVC = 0, int G0 = 0, int G1 = NGI, typename LoadFrag>
 __device__ __forceinline__ bool validate_fragments(f32x4 (&bf)[NCI][NGI], LoadFrag& load_frag, bool first_chunk, int spec,
                                                    int& spec_delay, int& spec_clean, SyncWs* sync, int& abort_flag,
-                                                   int& nretry) {
+                                                   int& nretry, bool* acc = nullptr, bool last = true) {
     bool retried = false;
     unsigned long long t_retry = 0;
-    if constexpr (NCI * NGI <= 2) {   // the common case -- every fragment already holds payload -- costs ONE ballot (with the
+    auto has_canary = [](f32x4 v, auto gi_tag) {
+        constexpr int gi = decltype(gi_tag)::value;
+        constexpr int left = NVC > 0 ? NVC - 4 * gi : 4;
+        return has_canary_masked<(left >= 4 ? 15 : (1 << (left > 0 ? left : 0)) - 1)>(v);
+    };
+    if constexpr (NCI * (G1 - G0) <= 2) {   // the common case -- every fragment already holds payload -- costs ONE ballot (with the
                                       // backward kernel's five fragments the joint test measured 0.05 us per step SLOWER)
         bool stale = false;
+        static_for<G0, G1>([&](auto gi_tag) {
 #pragma unroll
-        for (int gi = 0; gi < NGI; ++gi)
-#pragma unroll
-            for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][gi]);
+            for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][decltype(gi_tag)::value], gi_tag);
+        });
         if (!__any(stale)) goto validated;
     }
     for (;;) {
         asm volatile("" ::: "memory");                            // (keeps re-loads from being hoisted or merged)
         bool any = false;
-#pragma unroll
-        for (int gi = 0; gi < NGI; ++gi)
+        static_for<G0, G1>([&](auto gi_tag) {
+            constexpr int gi = decltype(gi_tag)::value;
 #pragma unroll
             for (int ci = 0; ci < NCI; ++ci)
-                if (__any(has_canary(bf[ci][gi]))) {
+                if (__any(has_canary(bf[ci][gi], gi_tag))) {
                     any = true;
                     load_frag(ci, gi);
                 }
+        });
         if (!any) break;
         ++nretry;
         retried = true;
@@ -194,6 +248,11 @@ __device__ __forceinline__ bool validate_fragments(f32x4 (&bf)[NCI][NGI], LoadFr
         }
     }
 validated:
+    if (acc) {
+        *acc |= retried;
+        retried = *acc;
+    }
+    if (!last) return retried;
     if (((spec >> 16) & 1) && first_chunk) {
         if (retried) {
             spec_delay = min(spec_delay + ((spec >> 18) & 3), 63);
@@ -1335,17 +1394,38 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     int scur = 0, sprev = NSLOT - 1;                    // slot written this step / read this step (= last step's)
     int spec_delay = spec & 0xFF, spec_clean = 0, nretry = 0;   // speculative protocol: see spec_timing()
 
+    // DS2_GI_PREFETCH (speculative protocol; see the forward kernel): the saved activations of step s + 1 are loaded right
+    // behind the hand-off stores of step s, not at the top of step s + 1 in front of its hand-off loads
+#ifndef DS2_GI_PREFETCH
+#define DS2_GI_PREFETCH 1
+#endif
+    constexpr bool GIPF = SPEC && DS2_GI_PREFETCH;
+    // Staged consumption (validate_fragments), measured round 4 at B = 10 / 8, us per step, all-at-once -> staged -> staged with
+    // the loads of successive fragments 2 sleeps apart: FORWARD 2.77 -> 2.73 -> 2.67-2.72 / 2.40 -> 2.30 -> 2.28 (and with the
+    // k-balanced deal 2.64 -> 2.66 -> 2.61 / 2.30 -> 2.30 -> 2.25): on; BACKWARD 2.92 -> 2.97 -> 3.0 / 2.41 -> 2.63 -> 2.50: off
+    // (five validations per step instead of one ballot-free pass cost more than the earlier start of the MFMAs brings).
+#ifndef DS2_STAGED_FWD
+#define DS2_STAGED_FWD 1
+#endif
+#ifndef DS2_STAGED_BWD
+#define DS2_STAGED_BWD 0
+#endif
+#ifndef DS2_STAGE_GAP
+#define DS2_STAGE_GAP 2
+#endif
+    constexpr bool STAGED = SPEC && DS2_STAGED_BWD;        // validate + multiply k group by k group (validate_fragments)
+    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
     for (int s = 0; s < T; ++s) {
         DS2_TICK(0);
         const int t = dir == 0 ? T - 1 - s : s;
-        const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
-        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
-        size_t row = 0, gbase = 0;
-        auto early_loads = [&]() {
+        float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
+        const size_t row = ((size_t)t * B + gb) * 2 + dir, gbase = row * 3 * H + gj;     // (of the CURRENT step: saved stores)
+        auto early_loads = [&](int t) {
+            dh = r = z = n = gn = hpv = 0.f;
             if (gate_ok) {
                 // saved activations of step t (written by the forward pass, an earlier launch): plain loads
-                row = ((size_t)t * B + gb) * 2 + dir;
-                gbase = row * 3 * H + gj;
+                const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
+                const size_t row = ((size_t)t * B + gb) * 2 + dir, gbase = row * 3 * H + gj;
                 dh = d_out[((size_t)t * B + gb) * H + gj];
                 r = G[gbase];
                 z = G[gbase + H];
@@ -1357,14 +1437,16 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         // signal-first: the polling wave polls FIRST, then waits for its own (by then old) stores, and only then issues
         // these loads -- a vmcnt wait behind freshly issued HBM loads would put their latency on the step's chain
         const bool poll_first = CAN && !SPEC && wave == SIGW && s > 0;
-        if (!poll_first) early_loads();
+        DS2_WTICK(0);
+        if (!poll_first && !(GIPF && s > 0)) early_loads(t);
+        DS2_WTICK(1);
         if (s > 0) {
             if (!SPEC) {
                 if (!DS2_DBG(dbg, 1) && wave == SIGW && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                     abort_flag = 1;
                 if (poll_first) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
-                    early_loads();
+                    early_loads(t);
                 }
                 DS2_TICK(1);
                 __syncthreads();
@@ -1391,12 +1473,15 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                                                         : OOB_OFFSET);
                 };
 #pragma unroll
-                for (int gi = 0; gi < NGI; ++gi)                   // k-group major: the MFMAs below consume in this order
+                for (int gi = 0; gi < NGI; ++gi) {                 // k-group major: the MFMAs below consume in this order
+                    if (STAGED && DS2_STAGE_GAP > 0 && gi > 0) __builtin_amdgcn_s_sleep(DS2_STAGE_GAP);
 #pragma unroll
                     for (int ci = 0; ci < NCI; ++ci) load_frag(ci, gi);
+                }
                 // every load of the chunk goes out before the first MFMA: left alone the scheduler sinks loads in between
                 // the MFMAs and keeps only 2-5 in flight, which throttles a phase bounded by bytes in flight
                 __builtin_amdgcn_sched_barrier(0);
+                DS2_WTICK(2);
                 auto products = [&]() {
 #pragma unroll
                     for (int rg = 0; rg < NRG; ++rg)
@@ -1414,8 +1499,32 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 };
                 // validate BEFORE the matrix work: a failed attempt then costs one more round trip for the stale fragments only.
                 // (Running the MFMAs optimistically first and repeating them after a re-load measured 15 % SLOWER per step.)
+                if constexpr (STAGED) {
+                    // staged: k group gi is validated right before its own MFMAs (see validate_fragments)
+#pragma unroll
+                    for (int rg = 0; rg < NRG; ++rg)
+#pragma unroll
+                        for (int ci = 0; ci < NCI; ++ci) acc[rg][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    bool racc = false;
+                    static_for<0, NGI>([&](auto gi_tag) {
+                        constexpr int gi = decltype(gi_tag)::value;
+                        validate_fragments<NCI, NGI, 0, gi, gi + 1>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync,
+                                                                    abort_flag, nretry, &racc, gi == NGI - 1);
+                        if (gi == 0) DS2_WTICK(3);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                                for (int rg = 0; rg < NRG; ++rg)
+                                    acc[rg][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[rg][gi][e], bf[ci][gi][e], acc[rg][ci], 0, 0, 0);
+                    });
+                } else {
                 if (SPEC) validate_fragments<NCI, NGI>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync, abort_flag, nretry);
+                DS2_WTICK(3);
                 products();
+                }
+                DS2_WTICK(4);
                 // fold the 16 per-block partials: two DPP adds leave each 16-lane row's sum in its lanes 12..15
                 // (all the DPP adds first, as independent chains, then ONE predicated region with the stores: written value
                 // by value the compiler emits add_dpp / s_nop / mov_dpp / saveexec / add / ds_write / restore exec per value)
@@ -1462,8 +1571,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             }
         }
         DS2_TICK(3);
+        DS2_WTICK(5);
         __syncthreads();
         DS2_TICK(4);
+        DS2_WTICK(6);
         // a wave gave up on a payload that never came (bounded re-loads): the flag is READ here, with the partial sums, and
         // TESTED before anything leaves the workgroup -- its LDS round trip is not a separate stop on the step's chain
         const int aborted = CAN ? abort_flag : 0;
@@ -1512,7 +1623,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 #undef DS2_QUAD_BCAST
             // speculative protocol: the stores of the PREVIOUS step (a step old) are complete before this step's payload goes
             // out -- a consumer that has seen this payload can rely on every canary this workgroup wrote before it
-            if (SPEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (SPEC) wait_vmcnt0();
+            DS2_WTICK(7);
             if (gate_ok && (jj & 3) == 0) {
                 const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, NSLOT * slot_floats * 4,
                                                                                       0x00020000);
@@ -1530,14 +1642,17 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 }
             }
         }
+        if (GIPF && s + 1 < T) early_loads(dir == 0 ? T - 2 - s : s + 1);      // the next step's, behind this step's payload
         DS2_TICK(5);
         if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (SPEC && (spec & (1 << 17))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // self-timed: see spec_timing()
         sprev = scur;
         scur = scur == NSLOT - 1 ? 0 : scur + 1;
         DS2_TICK(6);
+        DS2_WTICK(8);
         __syncthreads();
         DS2_TICK(7);
+        DS2_WTICK(9);
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
         if (!SPEC && tid == SIGW * 64 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1551,6 +1666,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         // step's arrival add -- and before its early loads are issued, so the wait never covers a fresh HBM load.  The
         // polling wave (0) starts polling at once instead and drains after its poll has matched (its stores are old by then).
         if (CAN && !SPEC && wave != SIGW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DS2_WTICK(10);
     }
     DS2_RETRY_FLUSH(nretry);
     if (tid == SIGW * 64) leave_kernel(sync);   // the thread whose arrival adds must have been performed first
@@ -1575,6 +1691,20 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 // ----------------------------------------------------------------------------------------------------------
 constexpr int FWD4_PITCH = NWP * 4 + 4;   // 32 partials (wave, lane row) + 4: 16-B aligned, rows spread over banks
 
+// ---- the k-BALANCED deal (round 4; template parameter KPL > 0) ------------------------------------------------------
+// The deal above hands k out in groups of 64 (one dwordx4 per lane feeds 16 instructions): H = 800 is 12.5 groups on 8 waves
+// x NGI = 2 slots, so the busiest SIMD (waves 0 and 4) executes 4 groups' worth of MFMAs where the average is 3.125 -- and
+// the matrix phase of a step ends with the busiest SIMD.  Here every one of the 32 lane rows (8 waves x 4) owns exactly
+// KPL = H / 32 consecutive k: lane row R = 4 wave + g owns k = KPL R .. KPL R + KPL - 1, an instruction still retires ONE k
+// per lane row (4 k per instruction, A broadcast from the block ABID names), so a wave issues KPL x NA instructions: 100
+// instead of 128 at H = 800 with four A sets, the same on every SIMD.  Lane (g, q, .) supplies the A operand (h) of the
+// instructions n = CH q .. CH q + CH - 1 of its row (CH = ceil(KPL / 4) consecutive k: 7 at KPL = 25; the last block of a
+// row has what is left: 4), as components of NLD = ceil(CH / 4) dwordx4 loads.  Exchange ring slot:
+// [batch quad][wave 8][ld NLD][kk = 4 g + q][rows][4]: lane l of a wave-load reads bytes 16 l .. 16 l + 15 of one contiguous
+// KB as before.  Components past a lane's share (m >= CH: the same for every lane, a compile-time mask; whole loads past
+// the last block's share: an out-of-range offset, i.e. zeros) belong to nobody, are never written and never tested or
+// multiplied.  Selected when H % 32 == 0, the last block's share is whole loads, and there is no B set (launcher).
+
 template <int Q>
 __device__ __forceinline__ float dpp_quad_add(float v) {   // Q = quad_perm selector: 0xB1 = xor 1, 0x4E = xor 2
     const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), Q, 0xF, 0xF, true);
@@ -1589,7 +1719,7 @@ __device__ __forceinline__ float dpp_quad_add(float v) {   // Q = quad_perm sele
 // slices x 3 parts x 2 directions = 240 workgroups -- the forward pass has the chip to itself, so it can take 240 CUs where
 // the backward pass leaves 52 to the weight-gradient GEMMs; 15 row groups = (r0-3) (r4 z0 z1 z2) (z3 z4 n0 n1) (n2 n3 n4 -):
 // the last A set's fourth block multiplies zeros (16 MFMAs per k instead of 18: 2.99 -> 2.9 us per step at B = 10).
-template <int NGI, int P, int NBT, int PROTO, int UGX = 0>
+template <int NGI, int P, int NBT, int PROTO, int UGX = 0, int KPL = 0>
 __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        float* __restrict__ hout,
                                                                        const float* __restrict__ w_hh,
@@ -1603,6 +1733,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     static_assert(NRGI % 4 != 1, "a single left-over row group is not dealt");
     constexpr int CGW = P == 1 ? CGC : (P == 2 ? 2 : 1);   // batch quads per chunk (register budget)
     constexpr int RPP = (NWP * 64) / (4 * UNITS);          // batch rows the gate role covers per pass (16, 8, 5)
+    // k-balanced deal (see above): CH = k per (lane row, block), NLD = dwordx4 loads per lane, NFR = fragments per quad
+    constexpr bool KB = KPL > 0;
+    constexpr int CH = KB ? (KPL + 3) / 4 : 1, NLD = KB ? (CH + 3) / 4 : 1, NFR = KB ? NLD : NGI;
+    static_assert(!KB || NBS == 0, "the k-balanced deal has no B set");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1617,7 +1751,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         return;
     }
     const int ncg = (nb + 3) >> 2;
-    const int ng = (H + 63) >> 6;
+    const int ng = KB ? NWP * NLD : (H + 63) >> 6;            // 64-float groups per batch row of a ring slot
     const int slot_floats = ng * 64 * nb;
     constexpr bool SPEC = PROTO != 0, CAN = SPEC;             // protocols: see the backward kernel and CANARY_BITS
     constexpr int NSLOT = SPEC ? 4 : 2;
@@ -1626,13 +1760,23 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     if (tid == 0) abort_flag = 0;
 
     // resident weights (B operands): set A a, block q = row group 4 a + q; set B: block q = pair q >> 1, row group 4 NA + (q & 1)
-    f32x4 wA[NA][NGI][4], wB[NBS > 0 ? NBS : 1][NGI][2];
+    f32x4 wA[KB ? 1 : NA][KB ? 1 : NGI][4], wB[NBS > 0 ? NBS : 1][KB ? 1 : NGI][2];
+    float wK[NA][KB ? KPL : 1];                         // k-balanced deal: weight of row (4 a + q, li) at k = KPL R + n
     auto weight_row = [&](int rgi) {
         const int gate = rgi / UG, unit = j0 + 4 * (rgi % UG) + li;
         return (rgi < NRGI && unit < H) ? w_hh + ((size_t)dir * 3 * H + (size_t)gate * H + unit) * H : nullptr;
     };
+    if constexpr (KB) {
+        const int kbase = KPL * (4 * wave + g);
 #pragma unroll
-    for (int gi = 0; gi < NGI; ++gi) {
+        for (int a = 0; a < NA; ++a) {
+            const float* row = weight_row(4 * a + q);
+#pragma unroll
+            for (int n = 0; n < KPL; ++n) wK[a][n] = (row && kbase + n < H) ? row[kbase + n] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int gi = 0; gi < (KB ? 0 : NGI); ++gi) {
         const int k0 = 64 * (wave + NWP * gi) + 16 * g;
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
@@ -1666,6 +1810,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     for (int bt = 0; bt < NBT; ++bt) {
         const int lb = bt * RPP + nn;
         const int rows4 = min(4, nb - (lb & ~3)) * 4;
+        if constexpr (KB) {                             // unit gj = k: lane row R, instruction n, block qs, component m
+            const int R = gj / KPL, n = gj % KPL, qs = n / CH, m = n % CH;
+            hoff[bt] = (nn < RPP && lb < nb && gj < H && gpart == 0)
+                           ? (lb >> 2) * ng * 256 + ((((R >> 2) * NLD + (m >> 2)) * 16 + 4 * (R & 3) + qs)) * rows4 + (lb & 3) * 4 + (m & 3)
+                           : -1;
+        } else
         hoff[bt] = (nn < RPP && lb < nb && gj < H && gpart == 0)
                        ? (lb >> 2) * ng * 256 + (gj >> 2) * rows4 + (lb & 3) * 4 + (gj & 3) : -1;
         if (CAN && hoff[bt] >= 0) {                     // slot 0 (and 1) may hold an earlier launch's payload
@@ -1684,14 +1834,25 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     int scur = 0, sprev = NSLOT - 1;                    // slot written this step / read this step (= last step's)
     int spec_delay = spec & 0xFF, spec_clean = 0, nretry = 0;   // speculative protocol: see spec_timing()
 
+    // DS2_GI_PREFETCH (speculative protocol): the gate pre-activations of step s + 1 are loaded right behind the hand-off stores
+    // of step s instead of at the top of step s + 1 -- a wave's vector-memory operations complete in issue order, so loads
+    // issued at a step's top stand in front of that step's hand-off loads, and they take slots of the CU's miss queue while
+    // the hand-off loads are in flight (tools/gru_wave_timing.py: the second half of a step's hand-off loads lands a round
+    // trip after the first)
+#ifndef DS2_GI_PREFETCH
+#define DS2_GI_PREFETCH 1
+#endif
+    constexpr bool GIPF = SPEC && DS2_GI_PREFETCH;
+    constexpr bool STAGED = SPEC && DS2_STAGED_FWD;        // validate + multiply fragment by fragment (validate_fragments)
+    float gi_r[NBT], gi_z[NBT], gi_n[NBT];
     for (int s = 0; s < T; ++s) {
         const int t = dir == 0 ? s : T - 1 - s;
-        float gi_r[NBT], gi_z[NBT], gi_n[NBT], sv_a[NBT], sv_g[NBT], sv_h[NBT];
-        auto early_loads = [&]() {                      // independent of h: issued before the wait
+        float sv_a[NBT], sv_g[NBT], sv_h[NBT];
+        auto early_loads = [&](int t) {                 // independent of h: issued before the wait
 #pragma unroll
             for (int bt = 0; bt < NBT; ++bt) {
                 const int lb = bt * RPP + nn;
-                gi_r[bt] = gi_z[bt] = gi_n[bt] = sv_a[bt] = sv_g[bt] = sv_h[bt] = 0.f;
+                gi_r[bt] = gi_z[bt] = gi_n[bt] = 0.f;
                 if (nn < RPP && lb < nb && gj < H) {
                     const size_t gbase = (((size_t)t * B + b0 + lb) * 2 + dir) * 3 * H + gj;
                     gi_r[bt] = G[gbase];
@@ -1703,14 +1864,18 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         // signal-first: the polling wave polls first, drains its (old) stores, then issues these loads (see the backward
         // kernel): a vmcnt wait must never sit behind freshly issued HBM loads
         const bool poll_first = CAN && !SPEC && wave == 0 && s > 0;
-        if (!poll_first) early_loads();
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) sv_a[bt] = sv_g[bt] = sv_h[bt] = 0.f;
+        DS2_WTICK(0);
+        if (!poll_first && !(GIPF && s > 0)) early_loads(t);
+        DS2_WTICK(1);
         if (s > 0) {
             if (!SPEC) {
                 if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                     abort_flag = 1;
                 if (poll_first) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
-                    early_loads();
+                    early_loads(t);
                 }
                 __syncthreads();
                 if (abort_flag) return;
@@ -1719,29 +1884,63 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
             auto chunk = [&](int c, auto nci_tag) {
                 constexpr int NCI = decltype(nci_tag)::value;
-                f32x4 bf[NCI][NGI];
+                f32x4 bf[NCI][NFR];
                 // accumulation chains per set and quad (by e parity): with four or more A sets one chain per set keeps the
                 // matrix pipe fed (B = 10: 2.81 -> 2.77 us per step without the 16 adds that join two), below that two
                 constexpr int NCH = NA >= 4 ? 1 : 2;
                 f32x4 accA[NA][NCI][NCH], accB[NBS > 0 ? NBS : 1][NCI][NCH];
                 if (SPEC && c == 0)                                // before the step's FIRST hand-off loads only
                     for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
+                // (timing builds: dbg bit 8 = waves 0-3 issue their hand-off loads ~0.2 us late, bit 9 = waves 4-7 -- which
+                // half of the waves gets its data first?)
+                if ((DS2_DBG(dbg, 256) && wave < 4) || (DS2_DBG(dbg, 512) && wave >= 4))
+                    for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(1);
                 auto load_frag = [&](int ci, int gi) {
                     const int gq = wave + NWP * gi;                // wave-uniform k group
                     const int cg = c * CGW + ci;
                     const int rows = min(4, nb - 4 * cg);
                     const int kk = 4 * g + q;
+                    if constexpr (KB) {
+                        // gi = load index: components m = 4 gi .. 4 gi + 3 of this block's share (k = KPL R + CH q + m);
+                        // a load wholly past the share (the row's last block) or past the batch rows reads nothing
+                        bf[ci][gi] = LOAD_HANDOFF(rs_x, (CH * q + 4 * gi < KPL && 4 * gi < CH && li < rows)
+                                                            ? (cg * ng * 256 + (((wave * NLD + gi) * 16 + kk) * rows + li) * 4) * 4
+                                                            : OOB_OFFSET);
+                        return;
+                    }
                     // rows past the batch and k past H load nothing (out-of-range offset -> 0)
                     bf[ci][gi] = LOAD_HANDOFF(rs_x, (64 * gq + 4 * kk < H && li < rows)
                                                         ? (cg * ng * 256 + ((gq * 16 + kk) * rows + li) * 4) * 4
                                                         : OOB_OFFSET);
                 };
 #pragma unroll
-                for (int gi = 0; gi < NGI; ++gi)
+                for (int gi = 0; gi < NFR; ++gi) {
+                    if (STAGED && DS2_STAGE_GAP > 0 && gi > 0) __builtin_amdgcn_s_sleep(DS2_STAGE_GAP);
 #pragma unroll
                     for (int ci = 0; ci < NCI; ++ci) load_frag(ci, gi);
+                }
                 __builtin_amdgcn_sched_barrier(0);                 // every load out before the first MFMA
+                DS2_WTICK(2);
                 auto products = [&]() {
+                if constexpr (KB) {
+#pragma unroll
+                    for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                        for (int h2 = 0; h2 < NCH; ++h2)
+#pragma unroll
+                            for (int a = 0; a < NA; ++a) accA[a][ci][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    // instruction n: one k per lane row (k = KPL R + n), A = h from the row's block n / CH, component n % CH
+                    static_for<0, KPL>([&](auto n_tag) {
+                        constexpr int n = decltype(n_tag)::value, ABID = n / CH, m = n % CH;
+#pragma unroll
+                        for (int a = 0; a < NA; ++a)
+#pragma unroll
+                            for (int ci = 0; ci < NCI; ++ci)
+                                accA[a][ci][n & (NCH - 1)] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                                    bf[ci][m >> 2][m & 3], wK[a][n], accA[a][ci][n & (NCH - 1)], 2, ABID, 0);
+                    });
+                    return;
+                }
                 // two chains per set and quad (e parity): a wave needs ~12 independent chains to issue every 10 cycles
 #pragma unroll
                 for (int ci = 0; ci < NCI; ++ci)
@@ -1776,8 +1975,65 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 };
                 // validate BEFORE the matrix work: a failed attempt then costs one more round trip for the stale fragments only.
                 // (Running the MFMAs optimistically first and repeating them after a re-load measured 15 % SLOWER per step.)
+                if constexpr (STAGED) {
+                    // staged: a fragment is validated right before its own MFMAs (see validate_fragments)
+#pragma unroll
+                    for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                        for (int h2 = 0; h2 < NCH; ++h2) {
+#pragma unroll
+                            for (int a = 0; a < NA; ++a) accA[a][ci][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            accB[0][ci][h2] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    bool racc = false;
+                    static_for<0, NFR>([&](auto fr_tag) {
+                        constexpr int gi = decltype(fr_tag)::value;
+                        validate_fragments<NCI, NFR, KB ? CH : 0, gi, gi + 1>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync,
+                                                                              abort_flag, nretry, &racc, gi == NFR - 1);
+                        if (gi == 0) DS2_WTICK(3);
+                        if constexpr (KB) {
+                            static_for<0, KPL>([&](auto n_tag) {
+                                constexpr int n = decltype(n_tag)::value, ABID = n / CH, m = n % CH;
+                                if constexpr ((m >> 2) == gi) {
+#pragma unroll
+                                    for (int a = 0; a < NA; ++a)
+#pragma unroll
+                                        for (int ci = 0; ci < NCI; ++ci)
+                                            accA[a][ci][n & (NCH - 1)] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                                                bf[ci][m >> 2][m & 3], wK[a][n], accA[a][ci][n & (NCH - 1)], 2, ABID, 0);
+                                }
+                            });
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+#define DS2_FWD4_MFMA_A(ABID)                                                                                      \
+    _Pragma("unroll") for (int a = 0; a < NA; ++a) _Pragma("unroll") for (int ci = 0; ci < NCI; ++ci)              \
+        accA[a][ci][e & (NCH - 1)] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[ci][gi][e], wA[a][gi][ABID][e], accA[a][ci][e & (NCH - 1)], 2, ABID, 0);
+#define DS2_FWD4_MFMA_B(ABID)                                                                                      \
+    if constexpr (NBS > 0) {                                                                                       \
+        _Pragma("unroll") for (int ci = 0; ci < NCI; ++ci) accB[0][ci][e & (NCH - 1)] =                            \
+            __builtin_amdgcn_mfma_f32_4x4x1f32(bf[ci][gi][e], wB[0][gi][ABID][e], accB[0][ci][e & (NCH - 1)], 1, ABID, 0); \
+    }
+                                DS2_FWD4_MFMA_A(0)
+                                DS2_FWD4_MFMA_B(0)
+                                DS2_FWD4_MFMA_A(1)
+                                DS2_FWD4_MFMA_B(1)
+                                DS2_FWD4_MFMA_A(2)
+                                DS2_FWD4_MFMA_A(3)
+#undef DS2_FWD4_MFMA_A
+#undef DS2_FWD4_MFMA_B
+                            }
+                        }
+                    });
+                } else {
+                if constexpr (KB) {
+                    if (SPEC) validate_fragments<NCI, NFR, CH>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync, abort_flag, nretry);
+                } else
                 if (SPEC) validate_fragments<NCI, NGI>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync, abort_flag, nretry);
+                DS2_WTICK(3);
                 products();
+                }
+                DS2_WTICK(4);
                 // D register i = batch row i of the quad; lane (g, q, li): set A a -> gate row 4 (4 a + q) + li, k
                 // sub-index g; set B -> gate row 4 (4 NA + (q & 1)) + li, k sub-indices (g, q >> 1): one DPP add folds
                 // the two pairs
@@ -1815,12 +2071,15 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 }
             }
         }
+        DS2_WTICK(5);
         __syncthreads();
+        DS2_WTICK(6);
         // a wave gave up on a payload that never came (bounded re-loads): read with the partial sums, tested before the
         // stores (see the backward kernel)
         const int aborted = CAN ? abort_flag : 0;
         // speculative protocol: the previous step's stores (a step old) are complete before this step's payload goes out
-        if (SPEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (SPEC) wait_vmcnt0();
+        DS2_WTICK(7);
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {
             const int lb = bt * RPP + nn;
@@ -1859,11 +2118,14 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
             }
         }
         if (aborted) return;
+        if (GIPF && s + 1 < T) early_loads(dir == 0 ? s + 1 : T - 2 - s);             // the next step's, behind this step's payload
         if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
         if (SPEC && (spec & (1 << 17))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // self-timed: see spec_timing()
         sprev = scur;
         scur = scur == NSLOT - 1 ? 0 : scur + 1;
+        DS2_WTICK(8);
         __syncthreads();
+        DS2_WTICK(9);
         // (dbg bit 6, tests only: workgroup 0 'loses' its arrival of step 2 -> every waiter must time out, not hang)
         if (!SPEC && tid == 0 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1884,6 +2146,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         // the drain, AFTER the signal (see CANARY_BITS): before the next step's arrival add and its early loads; the polling
         // wave drains after its poll instead
         if (CAN && !SPEC && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DS2_WTICK(10);
     }
     DS2_RETRY_FLUSH(nretry);
     if (tid == 0) leave_kernel(sync);
@@ -2053,6 +2316,23 @@ bool launch_bwd_persistent_p2b(float* G, float* ghn, const float* hout, const fl
     return false;
 }
 
+// The k-balanced deal of the forward 4x4x1 kernel (see the kernel): for which shapes it is built and selected.  KPL = H / 32
+// k per lane row; the speculative single-quad case only (one batch quad per workgroup: B <= 12 with three parts, <= 8 with two);
+// the row's last block must hold whole dwordx4 loads.  DS2_GRU_FWD_KBAL=0 switches it off (A/B timing).
+inline int kbal_kpl(int H, int rows_per_part, int proto) {
+    // Measured round 4 (B = 10 / 8, us per forward step, old deal -> balanced).  With round 3's step structure: 2.79 -> 2.81 /
+    // 2.30 -> 2.28 -- the busiest SIMD issues 22 % fewer MFMAs and the step does not move, because the matrix phase of the waves
+    // whose hand-off data lands first ran under the wait for the rest.  With the saved-activation loads prefetched, the
+    // compiler's stray vmcnt(0) gone and staged consumption (all round 4) the matrix pipe is on the chain: 2.73 -> 2.66
+    // (2.67-2.72 -> 2.61 with the 2-sleep gap between fragment loads) / 2.30 -> 2.30 (2.28 -> 2.25).
+    const char* e = getenv("DS2_GRU_FWD_KBAL");
+    if (e && e[0] == '0') return 0;
+    if (H % 32 != 0 || rows_per_part > 4 || proto == 0) return 0;
+    const int kpl = H / 32, ch = (kpl + 3) / 4, last = kpl - 3 * ch;
+    if (last < 0 || (last != ch && last % 4 != 0)) return 0;
+    return kpl;
+}
+
 template <int P, int NBT, int PROTO, int UGX = 0>
 bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
                             int H, int dbg, hipStream_t st) {
@@ -2062,6 +2342,18 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
     dim3 grid(ds2_cdiv(H, UNITS), 2, P), block(NWP * 64);
     const int ncg = (ds2_cdiv(B, P) + 3) / 4;
     const size_t lds = (size_t)ncg * 4 * 3 * UNITS * FWD4_PITCH * sizeof(float);
+    // k-balanced deal: built for H = 800 (KPL = 25), the BASELINE configs' width, in the forms without a B set
+    if constexpr (PROTO != 0 && NBT == 1 && ((UGX ? 3 * UGX : 6 * P) % 4 != 2)) {
+        if (kbal_kpl(H, ds2_cdiv(B, P), PROTO) == 25) {
+            auto kern = &gru_fwd_persistent4_kernel<1, P, NBT, PROTO, UGX, 25>;
+            if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return false;
+            if (!grid_is_coresident(kern, grid, lds)) return false;
+            hipLaunchKernelGGL(kern, grid, block, lds, st, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, spec_timing(0));
+            return true;
+        }
+    }
 #define DS2_FWD4_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (lds > 64 * 1024 &&                                                                                   \

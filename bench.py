@@ -14,6 +14,7 @@ rule, codes/sampler.py:119-125), per-GPU batch stays 10 -> weak scaling; value =
 max-over-ranks time.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -128,6 +129,7 @@ def gpu_parity_side(model, trainer, front, decoder, plan_entry, dev):
     ops.check_async_errors()
     return {'state_dict': sd, 'plan_entry': plan_entry, 'logits': acts.transpose(0, 1).cpu().numpy(),
             'loss_sum': float(loss) * len(bin_[0]), 'gnorm': float(gnorm), 'strings': [s[0] for s in strings],
+            'argmax': probs.argmax(-1).cpu().numpy(),
             'out_sizes': sizes.cpu().numpy(), 'labels_txt': None}
 
 
@@ -210,6 +212,14 @@ def cpu_baseline(plan, budget_s=60.0, full=True, parity=None):
                 'grad_norm_rel_err': abs(parity['gnorm'] - seen['gnorm']) / seen['gnorm'],
                 'greedy_strings_equal': bool(parity['strings'] == list(cpu_strings)),
                 'greedy_strings_differing': int(sum(a != c for a, c in zip(parity['strings'], cpu_strings))),
+                'greedy_string_chars': int(sum(len(a) for a in parity['strings'])),
+                # every valid frame's eval-mode argmax (what the strings are collapsed from; the strings of a barely trained
+                # model can be short): frames where the two paths pick different classes, and how close the oracle's two best
+                # classes are there (a tie at fp32 round-off is not a disagreement)
+                'argmax_frames': int(valid.sum()),
+                'argmax_frames_differing': int(((parity['argmax'] != probs.argmax(-1)) & valid).sum()),
+                'argmax_differing_frames_min_margin': (lambda m: float(m.min()) if m.size else None)(
+                    (np.sort(probs, -1)[..., -1] - np.sort(probs, -1)[..., -2])[(parity['argmax'] != probs.argmax(-1)) & valid]),
                 'out_sizes_equal': bool(np.array_equal(parity['out_sizes'], sizes)),
                 'tolerances': 'north_star: logits 1e-3 abs, CTC loss 1e-4 rel, greedy strings identical',
                 'what': 'HIP path (STFT frontend -> model -> CTC -> backward) against the CPU oracle (oracle/: numpy STFT, '
@@ -382,6 +392,7 @@ def timed_steps(step, n, warmup, use_dist):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.collect()                  # (a generation-2 collection inside a 0.3 s timed region is a 5 % outlier; collect now)
     stamps = []
     t0 = time.time()
     p0 = time.perf_counter()
@@ -515,11 +526,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    from codes.utils.dist_utils import assert_no_fallbacks, data_parallel_env
     if world > 1 or os.environ.get('DS2_BENCH_FORCE_DIST') == '1':
-        # With a process group there are more streams (the all-reduce stream, RCCL's own) than the HIP runtime's default
-        # four hardware queues serve well: measured on one rank, the step loses 12 % (308 k vs 352 k frames/s) with the
-        # default and nothing with two or three queues.  Read by the runtime at its first call, so set before any.
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '3')
+        # hardware-queue count and RCCL channel cap: ONE function shared with train.py (codes/utils/dist_utils.py); read by
+        # the runtime / RCCL when they start, so applied before the first torch.cuda call
+        data_parallel_env()
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X: the product path has no CPU fallback')
     # a benchmark must never report the launch-per-step fall-back's rate as the product's: a persistent recurrence launch
@@ -532,9 +543,6 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29531')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        # The recurrence kernels need ~204 of the 256 CUs co-resident; cap RCCL's kernels at 32 workgroups so a gradient
-        # all-reduce running beside them (on the 52 CUs they leave free) can never keep one from starting.
-        os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
         dist.init_process_group('nccl', init_method='env://')
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
@@ -660,6 +668,8 @@ def main():
                'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'),
                'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES')}
         note('data-parallel diagnostics done: %s' % json.dumps(ddp))
+        # the --gpus N self-check: a fall-back anywhere FAILS the run (every rank raises: the count is the all-reduced sum)
+        assert_no_fallbacks(ddp['persistent_to_step_fallbacks'], 'bench.py --gpus %d' % world)
 
     # BASELINE configs[3] at N > 1: 64 x 15 s over 8 GPUs = 8 clips of 15 s per rank (every rank, same barrier protocol)
     cfg3 = None
@@ -770,7 +780,9 @@ def main():
                                                     else ddp['persistent_to_step_fallbacks']),
                    'ms_per_step_rank0': {'median': round(1e3 * pct_of(per_sorted, 0.5), 3),
                                          'p10': round(1e3 * pct_of(per_sorted, 0.1), 3),
-                                         'p90': round(1e3 * pct_of(per_sorted, 0.9), 3)},
+                                         'p90': round(1e3 * pct_of(per_sorted, 0.9), 3),
+                                         'max': round(1e3 * per_sorted[-1], 3),
+                                         'per_step': [round(1e3 * v, 2) for v in per]},
                    'frames_per_s_per_step_rank0': {'median': round(pct_of(step_rates, 0.5), 1),
                                                    'p10': round(pct_of(step_rates, 0.1), 1),
                                                    'p90': round(pct_of(step_rates, 0.9), 1)},

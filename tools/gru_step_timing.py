@@ -2,6 +2,9 @@ import os, sys, subprocess, json
 _ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(_ROOT, 'aes-lac-2018_amd')); sys.path.insert(0, _ROOT)
 import torch, numpy as np
+from ds2hip import lib
+if os.environ.get('DS2_LIB_VARIANT'):          # libds2hip_<variant>.so (csrc/build.py --variant / build_variant)
+    lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), 'libds2hip_%s.so' % os.environ['DS2_LIB_VARIANT'])
 from ds2hip import ops
 t, bsz, hid = 405, int(os.environ.get('BSZ', '10')), 800
 torch.manual_seed(0)

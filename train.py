@@ -25,6 +25,7 @@ from codes.engine import create_evaluator, create_trainer  # noqa: E402
 from codes.transforms import BatchSpectrogram, waveform_scale  # noqa: E402
 from codes.utils import model_utils as mu  # noqa: E402
 from codes.utils import training_utils as tu  # noqa: E402
+from codes.utils.dist_utils import data_parallel_env  # noqa: E402
 from codes.utils.io_utils import AttrDict, expand_values  # noqa: E402
 
 LOG = logging.getLogger('aes-lac-2018')
@@ -105,11 +106,8 @@ def main(argv=None):
     args.distributed = not args.local
     if args.distributed:
         # BEFORE the first torch.cuda call (is_available() already initialises the HIP runtime, which reads its flags
-        # once): three hardware queues serve the main / weight-gradient / all-reduce streams better than the default
-        # four (bench.py: 308 k -> 350 k frames/s on the RCCL path), and RCCL is kept at <= 32 workgroups so its kernels
-        # fit beside the recurrence kernels' ~204 co-resident workgroups.
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '3')
-        os.environ.setdefault('NCCL_MAX_NCHANNELS', '32')
+        # once): hardware-queue count and RCCL channel cap -- codes/utils/dist_utils.py, shared with bench.py
+        data_parallel_env()
     if not torch.cuda.is_available():
         raise RuntimeError('Training script requires GPU. :(')
     torch.manual_seed(42)
