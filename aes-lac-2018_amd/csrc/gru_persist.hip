@@ -91,12 +91,22 @@ struct SyncWs {            // lives in caller-provided device memory: zeroed ONC
 #define DS2_DBG(dbg, bit) 0
 #endif
 
+// s_waitcnt vmcnt(0) as the BUILTIN (simm16: vmcnt = 0, expcnt and lgkmcnt at their maxima = not waited for), not as inline
+// asm: the compiler's wait-count insertion cannot see into an asm statement, so behind one it still believes the wave's
+// earlier loads are in flight -- and when a later instruction touches one of their destination registers (the loop-carried
+// saved-activation registers of the 4x4x1 kernels) it inserts a vmcnt(0) of its OWN at that point, which then also waits for
+// whatever was issued in between: round 4 found such a wait right behind the hand-off stores (0.4 us per step waiting for
+// the write-through acknowledgements before the next loads could issue), and, in the round-3 kernels, at the top of every step.
+__device__ __forceinline__ void wait_vmcnt0() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+}
 // Called by thread 0 of every workgroup that leaves the kernel normally (not on the timeout path: there the host resets
 // the workspace).  The arrival adds of this workgroup have been performed at the memory side once vmcnt is 0; the
 // workgroup whose add to `done` comes last knows every other workgroup has stopped polling and adding, and zeroes the
 // counters with write-through stores: the next launch on the stream starts from zero without a memset in between.
 __device__ __forceinline__ void leave_kernel(SyncWs* sync) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmcnt0();
     const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
     const unsigned int prev = __hip_atomic_fetch_add(&sync->done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == total - 1) {
@@ -113,16 +123,6 @@ __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int 
 // hand-off payload load (a timing experiment with plain, L2-allocating loads showed no difference; a run-time
 // switch between the two forms here costs a branch and a vmcnt(0) join in front of the MFMAs)
 #define LOAD_HANDOFF(rs, off) load_sc1_b128(rs, off)
-// s_waitcnt vmcnt(0) as the BUILTIN (simm16: vmcnt = 0, expcnt and lgkmcnt at their maxima = not waited for), not as inline
-// asm: the compiler's wait-count insertion cannot see into an asm statement, so behind one it still believes the wave's
-// earlier loads are in flight -- and when a later instruction touches one of their destination registers (the loop-carried
-// saved-activation registers of the 4x4x1 kernels) it inserts a vmcnt(0) of its OWN at that point, which then also waits for
-// whatever was issued in between: round 4 found such a wait right behind the hand-off stores (0.4 us per step waiting for
-// the write-through acknowledgements before the next loads could issue), and, in the round-3 kernels, at the top of every step.
-__device__ __forceinline__ void wait_vmcnt0() {
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" ::: "memory");
-}
 constexpr int OOB_OFFSET = 0x7FFFFFF0;    // beyond any descriptor's num_records: the range-checked load returns 0
 __device__ __forceinline__ void store_sc1(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __r
             sv_n = n;
             sv_g = gh_n;
         }
-        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
+        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();   // every storing wave drains its hand-off store
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // saved activations are only read by later launches: keep them off the hand-off's critical path
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* 
                                __builtin_bit_cast(u32x4, hq));
             }
         }
-        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2b_kernel(float*
                 for (int c = 0; c < 3; ++c) store_sc1_b128(rs_w, base + c * 1024, planes[c]);
             }
         }
-        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __r
             sv_n = dn_pre;
             sv_g = dn_pre * r;
         }
-        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2_kernel(float* 
                 }
             }
         }
-        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2b_kernel(float*
             hand_off(sv_z, 1);
             hand_off(sv_g, 2);
         }
-        if (!DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             store_canary(my_ring + (size_t)sl * slot_floats + ho2);
         }
     }
-    if (CAN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (CAN) wait_vmcnt0();
     __syncthreads();
     if (SPEC) {
         // The speculative protocol has no per-step counters, so nothing in a step tells a consumer that a producer has even
@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 if (!DS2_DBG(dbg, 1) && wave == SIGW && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                     abort_flag = 1;
                 if (poll_first) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
+                    wait_vmcnt0();   // the polling wave's deferred drain
                     early_loads(t);
                 }
                 DS2_TICK(1);
@@ -1644,8 +1644,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         }
         if (GIPF && s + 1 < T) early_loads(dir == 0 ? T - 2 - s : s + 1);      // the next step's, behind this step's payload
         DS2_TICK(5);
-        if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (SPEC && (spec & (1 << 17))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // self-timed: see spec_timing()
+        if (!CAN && !DS2_DBG(dbg, 4)) wait_vmcnt0();
+        if (SPEC && (spec & (1 << 17))) wait_vmcnt0();   // self-timed: see spec_timing()
         sprev = scur;
         scur = scur == NSLOT - 1 ? 0 : scur + 1;
         DS2_TICK(6);
@@ -1665,7 +1665,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         // the drain, AFTER the signal: this step's stores (payload, next slot's canaries) are complete before the next
         // step's arrival add -- and before its early loads are issued, so the wait never covers a fresh HBM load.  The
         // polling wave (0) starts polling at once instead and drains after its poll has matched (its stores are old by then).
-        if (CAN && !SPEC && wave != SIGW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (CAN && !SPEC && wave != SIGW) wait_vmcnt0();
         DS2_WTICK(10);
     }
     DS2_RETRY_FLUSH(nretry);
@@ -1823,7 +1823,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
             for (int sl = 0; sl < CAHEAD; ++sl) store_canary(my_ring + (size_t)sl * slot_floats + hoff[bt]);
         }
     }
-    if (CAN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (CAN) wait_vmcnt0();
     __syncthreads();
     if (SPEC) {   // one counted rendezvous per launch: every producer's start-up canaries are in place before anybody reads
         if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1874,7 +1874,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                     abort_flag = 1;
                 if (poll_first) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the polling wave's deferred drain
+                    wait_vmcnt0();   // the polling wave's deferred drain
                     early_loads(t);
                 }
                 __syncthreads();
@@ -2119,8 +2119,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         }
         if (aborted) return;
         if (GIPF && s + 1 < T) early_loads(dir == 0 ? s + 1 : T - 2 - s);             // the next step's, behind this step's payload
-        if (!CAN && !DS2_DBG(dbg, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its hand-off store
-        if (SPEC && (spec & (1 << 17))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // self-timed: see spec_timing()
+        if (!CAN && !DS2_DBG(dbg, 4)) wait_vmcnt0();   // every storing wave drains its hand-off store
+        if (SPEC && (spec & (1 << 17))) wait_vmcnt0();   // self-timed: see spec_timing()
         sprev = scur;
         scur = scur == NSLOT - 1 ? 0 : scur + 1;
         DS2_WTICK(8);
@@ -2145,7 +2145,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         }
         // the drain, AFTER the signal (see CANARY_BITS): before the next step's arrival add and its early loads; the polling
         // wave drains after its poll instead
-        if (CAN && !SPEC && wave != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (CAN && !SPEC && wave != 0) wait_vmcnt0();
         DS2_WTICK(10);
     }
     DS2_RETRY_FLUSH(nretry);
