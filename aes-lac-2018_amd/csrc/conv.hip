@@ -465,11 +465,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 // steps: the d(out) chunk (32 channels x 64 steps, shared by the four waves) and the 13 input rows the 128 taps touch
 // (each read at 11 time shifts) are loaded once, coalesced, into LDS (double-buffered, one barrier per chunk); the MFMA
 // operands are conflict-free ds_read_b32.  Partial tiles are added into dW with float atomics as before.
-constexpr int WG_TC = 64, WG_PA = WG_TC + 1, WG_NROW = 13, WG_PB = WG_TC + 11;   // pitches 65 / 75: bank = row * 1 | 11 + t
-__global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __restrict__ in, const float* __restrict__ dout,
-                                                              int B, int FIN, int TIN, int FOUT, int TOUT, int nsplit,
-                                                              float* __restrict__ dw, float* __restrict__ dbias) {
-    constexpr int CIN = 32, KF = 21, KT = 11, SF = 2, NTOT = CIN * KF * KT, NB = WG_NROW * (WG_TC + KT - 1);
+// Round 4: the same kernel for conv1 (CIN = 1, 41 x 11 taps, time stride 2, 10 columns of zero padding on both sides: the
+// input window of a 64-step chunk is 2 x 64 + 10 columns starting at column 2 t0 - 10, read by the MFMA operand at stride 2).
+// conv1's direct kernel ran at 22 TFLOP/s (0.33 ms at the B = 10 bin mix, on the main stream behind everything else of the
+// backward pass); its 451 taps are 4 groups of 128.
+constexpr int WG_TC = 64, WG_PA = WG_TC + 1, WG_NROW = 13;   // pitch 65: bank = row + t
+template <int CIN, int KF, int SF, int ST, int PADT>
+__global__ __launch_bounds__(256) void conv_wgrad_lds_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                             int B, int FIN, int TIN, int FOUT, int TOUT, int nsplit,
+                                                             float* __restrict__ dw, float* __restrict__ dbias) {
+    constexpr int KT = 11, NTOT = CIN * KF * KT;
+    constexpr int WCOLS = ST * (WG_TC - 1) + KT;        // input columns a chunk touches per row: 74 (stride 1) / 137 (stride 2)
+    constexpr int WG_PB = WCOLS | 1;                    // odd pitch (75 / 137): consecutive rows start on different banks
+    constexpr int NB = WG_NROW * WCOLS, NBI = (NB + 255) / 256;
     __shared__ float sA[2][32 * WG_PA];
     __shared__ float sB[2][WG_NROW * WG_PB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __res
     const int n = n0 + wave * 32 + lr;
     const bool n_ok = n < NTOT;
     const int nn = n_ok ? n : n0;
-    const int boff = (nn / KT - r0) * WG_PB + nn % KT + lh;      // this lane's tap inside the staged input rows (+ k parity)
+    const int boff = (nn / KT - r0) * WG_PB + nn % KT + ST * lh;   // this lane's tap inside the staged input rows (+ k parity)
     const int aoff = lr * WG_PA + lh;
     const int tchunks = (TOUT + WG_TC - 1) / WG_TC;
     const int rows = B * FOUT;
@@ -487,18 +495,18 @@ __global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __res
     const int nchunks = myrows * tchunks;
     // staging roles: A -- channel tid / 8, eight steps from (tid % 8) * 8; B -- up to four scalars per thread
     const int a_co = tid >> 3, a_t = (tid & 7) * 8;
-    // B staging: element idx = tid + 256 i of the [13 rows][74 steps] window -> (row j, step x): fixed per thread for the launch
-    int b_src[4], b_dst[4], b_x[4];                     // source offset inside a (b, d) image (-1: nothing), LDS offset, step
+    // B staging: element idx = tid + 256 i of the [13 rows][WCOLS columns] window -> (row j, column x): fixed per thread for the launch
+    int b_src[NBI], b_dst[NBI], b_x[NBI];               // source offset inside a (b, d) image (-1: nothing), LDS offset, column
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NBI; ++i) {
         const int idx = tid + 256 * i;
-        const int j = idx / (WG_TC + KT - 1), x = idx - j * (WG_TC + KT - 1);
+        const int j = idx / WCOLS, x = idx - j * WCOLS;
         const int r = r0 + j, ci = r / KF, kf = r - ci * KF;
         b_src[i] = (idx < NB && r < CIN * KF) ? (ci * FIN + kf) * TIN + x : -1;
         b_dst[i] = idx < NB ? j * WG_PB + x : -1;
         b_x[i] = x;
     }
-    float ra[8], rb[4];
+    float ra[8], rb[NBI];
     int g_row = blockIdx.y, g_tc = 0;                    // (row, time chunk) of the NEXT gload: chunks walk time fastest
     auto gload = [&]() {
         const int row = g_row, t0 = g_tc * WG_TC;
@@ -519,15 +527,17 @@ __global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 8; ++e) ra[e] = (t0 + a_t + e < TOUT) ? ap[e] : 0.f;
         }
-        const float* bp = in + ((size_t)b * CIN * FIN + (size_t)SF * d) * TIN + t0;
+        const int c0 = ST * t0 - PADT;                    // first input column of the window (negative: zero padding)
+        const float* bp = in + ((size_t)b * CIN * FIN + (size_t)SF * d) * TIN + c0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = (b_src[i] >= 0 && t0 + b_x[i] < TIN) ? bp[b_src[i]] : 0.f;
+        for (int i = 0; i < NBI; ++i)
+            rb[i] = (b_src[i] >= 0 && c0 + b_x[i] >= 0 && c0 + b_x[i] < TIN) ? bp[b_src[i]] : 0.f;
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) sA[buf][a_co * WG_PA + a_t + e] = ra[e];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NBI; ++i)
             if (b_dst[i] >= 0) sB[buf][b_dst[i]] = rb[i];
     };
     f32x16 acc;
@@ -548,14 +558,14 @@ __global__ __launch_bounds__(256) void conv2_wgrad_lds_kernel(const float* __res
         if (sum_bias) {
 #pragma unroll 8
             for (int kp = 0; kp < WG_TC / 2; ++kp) {
-                const float a = pa[2 * kp], v = pb[2 * kp];
+                const float a = pa[2 * kp], v = pb[ST * 2 * kp];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v, acc, 0, 0, 0);
                 bsum += a;
             }
         } else {
 #pragma unroll 8
             for (int kp = 0; kp < WG_TC / 2; ++kp)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kp], pb[2 * kp], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * kp], pb[ST * 2 * kp], acc, 0, 0, 0);
         }
         if (c + 1 < nchunks) lstore(buf ^ 1);
         __syncthreads();
@@ -731,10 +741,19 @@ extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, in
     if (nsplit > ds2_cdiv(rows, 4)) nsplit = ds2_cdiv(rows, 4);
     if (nsplit < 1) nsplit = 1;
     dim3 grid(ntn, nsplit), block(256);
-    if (which == 1)
+    const bool lds_form = !(getenv("DS2_CONV_WGRAD_LDS") && getenv("DS2_CONV_WGRAD_LDS")[0] == '0');
+    if (which == 1 && lds_form) {
+        // conv1 through LDS (round 4): 4 groups of 128 taps x up to 256 row splits ~ 1000 workgroups, ~4 per CU
+        int split = 256;
+        if (getenv("DS2_CONV1_WGRAD_SPLIT")) split = atoi(getenv("DS2_CONV1_WGRAD_SPLIT"));
+        if (split > rows) split = rows;
+        if (split < 1) split = 1;
+        hipLaunchKernelGGL((conv_wgrad_lds_kernel<1, 41, 2, 2, 10>), dim3(ds2_cdiv(ntot, 128), split), block, 0, st, in, d_out, B,
+                           g.fin, tin, g.fout, tout, split, d_weight, d_bias);
+    } else if (which == 1)
         hipLaunchKernelGGL((conv_wgrad_kernel<1, 41, 11, 2, 2, 10>), grid, block, 0, st, in, d_out, B, g.fin, tin,
                            g.fout, tout, nsplit, d_weight, d_bias);
-    else if (!(getenv("DS2_CONV_WGRAD_LDS") && getenv("DS2_CONV_WGRAD_LDS")[0] == '0')) {
+    else if (lds_form) {
         // operands through LDS: 58 groups of 128 taps x 105 row splits = ~6000 workgroups, four rounds of the six a CU holds
         // (measured, ms, B = 10 / 32 / 64 / 8 x 15 s: 0.41 / 1.44 / 2.84 / 0.56; the direct kernel: 0.57 / 2.15 / 4.35 / 0.79;
         // 13 ... 53 splits: 0.42 - 0.49 at B = 10).  DS2_CONV_WGRAD_LDS = 0: the direct kernel, for A/B timing and tests
@@ -743,8 +762,8 @@ extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, in
         if (getenv("DS2_CONV_WGRAD_SPLIT")) split = atoi(getenv("DS2_CONV_WGRAD_SPLIT"));
         if (split > rows) split = rows;
         if (split < 1) split = 1;
-        hipLaunchKernelGGL(conv2_wgrad_lds_kernel, dim3(ngroups, split), block, 0, st, in, d_out, B, g.fin, tin, g.fout, tout,
-                           split, d_weight, d_bias);
+        hipLaunchKernelGGL((conv_wgrad_lds_kernel<32, 21, 2, 1, 0>), dim3(ngroups, split), block, 0, st, in, d_out, B, g.fin, tin,
+                           g.fout, tout, split, d_weight, d_bias);
     }
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<32, 21, 11, 2, 1, 0>), grid, block, 0, st, in, d_out, B, g.fin, tin,

@@ -83,11 +83,11 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned int*>(Wp), 0, w_bytes, 0x00020000);
 
-    f32x16 acc[NT];
+    f32x16 acc[NT], acc_lo[NT];                          // leading products / products with a residual term (split_mfma2)
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = acc_lo[i][r] = 0.f;
 
     // Software pipeline, NSET register sets: at the top of step s the loads of step s + NSET - 1 are issued (their scalar
     // offsets were read from the tap table a step earlier), then step s -- loaded NSET - 1 steps ago -- is split and
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < 3; ++q) b[q] = __builtin_bit_cast(bf16x8, rw[cur][q]);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] = split_mfma<NPROD>(a[i], b, acc[i]);
+        for (int i = 0; i < NT; ++i) split_mfma2<NPROD>(a[i], b, acc[i], acc_lo[i]);
     };
     for (int s = sbeg; s < send; s += NSET) {
         step(s, std::integral_constant<int, 0>{});
@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
         if (s + 3 < send) step(s + 3, std::integral_constant<int, 3>{});
     }
 
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] += acc_lo[i][r];
     const float bv = (bias != nullptr && blockIdx.y == 0) ? bias[lr] : 0.f;
     const int ocol = lr * g.o_col_stride;
 #pragma unroll

@@ -730,13 +730,13 @@ __device__ __forceinline__ void gemm_split_tile_body(char (&lds)[2][2][SPLIT_TIL
     constexpr int NI_ = MODE == 0 ? 2 : 1, NJ_ = MODE == 0 ? 2 : MODE;
     const int arow = MODE == 0 ? wm * 64 : wave * 32, bcol = MODE == 0 ? wn * 64 : 0;
 
-    f32x16 acc[NI_][NJ_];
+    f32x16 acc[NI_][NJ_], acc_lo[NI_][NJ_];           // leading products / products with a residual term (split_mfma2)
 #pragma unroll
     for (int i = 0; i < NI_; ++i)
 #pragma unroll
         for (int j = 0; j < NJ_; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = acc_lo[i][j][r] = 0.f;
 
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, b_bytes, 0x00020000);
@@ -785,7 +785,7 @@ __device__ __forceinline__ void gemm_split_tile_body(char (&lds)[2][2][SPLIT_TIL
         for (int i = 0; i < NI_; ++i)
 #pragma unroll
             for (int j = 0; j < NJ_; ++j) {
-                acc[i][j] = split_mfma<NPROD>(a[i], b[j], acc[i][j]);
+                split_mfma2<NPROD>(a[i], b[j], acc[i][j], acc_lo[i][j]);
             }
         // (unconditional as well: behind the last slab it fills a buffer nobody reads)
         split_store<A_KCONTIG>(lds[cur ^ 1][0], tid, ra[cur ^ 1]);
@@ -807,6 +807,12 @@ __device__ __forceinline__ void gemm_split_tile_body(char (&lds)[2][2][SPLIT_TIL
         slab(s, std::integral_constant<int, 0>{});
         if (s + 1 < nslab) slab(s + 1, std::integral_constant<int, 1>{});
     }
+#pragma unroll
+    for (int i = 0; i < NI_; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ_; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += acc_lo[i][j][r];
 
 #pragma unroll
     for (int i = 0; i < NI_; ++i)

@@ -29,7 +29,28 @@ __device__ __forceinline__ void split3(float a, float b, unsigned int& p1, unsig
     rb -= __builtin_bit_cast(float, p2 & 0xffff0000u);
     p3 = pack_bf16(ra, rb);
 }
-// the six (or nine) partial products of one 32 x 32 x 16 step
+// the six (or nine) partial products of one 32 x 32 x 16 step, into TWO accumulators (round 4): `hi` takes a1 b1, `lo` every
+// product that carries a residual term.  One accumulator for all of them ABSORBS the small products once the running sum is
+// large: with 4800 same-sign terms of order one the sum is ~10^4 (ulp 2^-10) while a1 b3 + a3 b1 contribute ~2^-16 per k --
+// each 16-k instruction's worth is below half an ulp and is rounded away, every time (the adversarial test of
+// tests/test_kernels_gpu.py: 1.8e-5 of the result lost, in the nine-product family too; the f32-input kernels lose 7.5e-6 on
+// the same operands).  Among themselves the residual products are 2^-8 of the leading ones, so `lo` keeps 8 more bits of
+// them; the two accumulators are added once, in the epilogue.  Same MFMA count, two independent chains.
+template <int NPROD>
+__device__ __forceinline__ void split_mfma2(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& hi, f32x16& lo) {
+    if (NPROD == 9) {
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[2], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[1], lo, 0, 0, 0);
+    }
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], lo, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
+}
+// (one accumulator: the recurrence kernels' K = 800 per step)
 template <int NPROD>
 __device__ __forceinline__ f32x16 split_mfma(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
     if (NPROD == 9) {

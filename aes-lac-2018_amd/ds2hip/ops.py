@@ -86,15 +86,18 @@ def decode_augment(pcm, offsets, tempos=None, gains_db=None, sample_rate=16000, 
     """pcm: concatenated int16 clips on the device; offsets: python list (B+1).  Returns (float clips concatenated,
     new offsets list).  ``tempos`` / ``gains_db`` (per clip, or None): the training-set augmentation -- WSOLA tempo,
     then gain in dB and 16-bit requantisation -- entirely on the device.  ``scale``: a sample of value q (int16, or the
-    requantised integer after augmentation) comes out as q * scale (``amplitude_scale``)."""
+    requantised integer after augmentation) comes out as q * scale (``amplitude_scale``).
+
+    The 16-bit requantisation belongs to the GAIN step (sox writes a 16-bit file at the end of ``tempo T gain G``,
+    codes/transforms.py:185-218, and the reference never draws one without the other): it happens exactly when ``gains_db`` is
+    given, at every amplitude scale.  A tempo-only call (a diagnostic path: the WSOLA kernel against its specification) returns
+    the float WSOLA output times ``scale / UNIT_SCALE`` -- the same samples at every scale, up to that factor."""
     import numpy as np
     wav = _empty((pcm.numel(),), pcm)
     if tempos is None and gains_db is None:
         lib.call('ds2_pcm16_to_float', pcm, pcm.numel(), float(scale), wav)
         return wav, list(offsets)
     lib.call('ds2_pcm16_to_float', pcm, pcm.numel(), UNIT_SCALE, wav)      # the augmentation works on [-1, 1)
-    if gains_db is None and scale != UNIT_SCALE:
-        gains_db = [0.0] * (len(offsets) - 1)        # the 16-bit output format still applies: requantise, then scale
     bsz = len(offsets) - 1
     lens = [offsets[i + 1] - offsets[i] for i in range(bsz)]
     if tempos is not None:
@@ -117,6 +120,8 @@ def decode_augment(pcm, offsets, tempos=None, gains_db=None, sample_rate=16000, 
         g = torch.tensor([10.0 ** (float('{:.3f}'.format(v)) / 20.0) for v in gains_db], dtype=torch.float32)
         offs_d = upload_small(torch.tensor(list(offsets), dtype=torch.int64), pcm.device)
         lib.call('ds2_gain_requantize', wav, offs_d, upload_small(g, pcm.device), bsz, float(scale), wav)
+    elif scale != UNIT_SCALE:
+        wav.mul_(float(scale) / UNIT_SCALE)
     return wav, list(offsets)
 
 

@@ -79,6 +79,49 @@ def test_gemm_split_operand_kernels_are_as_accurate_as_the_f32_kernels(ops, ta, 
     assert err[6][0] <= 3e-6 and err[0][0] <= 3e-6, err               # and all of them are fp32-grade in absolute terms
 
 
+def test_gemm_six_products_adversarial_aligned_residuals(ops):
+    """The six-product family leaves out a2 b3 + a3 b2 + a3 b3 of every product.  The WORST case for it: both residual
+    terms of every operand element as large as round-to-nearest allows and of the SAME sign along the whole of k, so that
+    what is left out adds up instead of averaging out -- at the model's deepest contraction, K = 4800 (the dX GEMM).
+    Element pattern: 1.m + 0.1111111|0|111111 (binary, at 2^-8): a1 = 1.m, a2 = +(2^-8 - 2^-16) (99.6 % of half an ulp of
+    a1), a3 = +(2^-17 - 2^-23); every product then misses 2 a2 a3 + a3^2 ~ 2^-24 of itself, all with one sign.
+    What the case showed when it was first run (round 4): the dropped products are invisible -- the nine-product family, which
+    leaves nothing out, had exactly the six-product family's error -- but fp32 ACCUMULATION is not: with one accumulator per
+    output the small partial products (a1 b3, a3 b1: 2^-16 of a term) were rounded away against a running sum of ~10^4, every
+    time: 1.8e-5 of the result lost, against 7.5e-6 for the f32-input kernels (whose own accumulation of 4800 same-sign terms
+    is biased too).  Since then the residual-carrying products have an accumulator of their own (split_bf16.h::split_mfma2):
+    1.5e-6.  Asserted: six == nine (the dropped terms stay below everything else), and the split families are no worse than
+    the f32-input kernels on their worst case."""
+    k, m, n = 4800, 256, 256
+    rng = np.random.default_rng(9)
+    resid = (2.0 ** -8 - 2.0 ** -16) + (2.0 ** -17 - 2.0 ** -23)     # 0.1111111|0|111111 at 2^-8: a2 rounds DOWN, a3 > 0
+
+    def operand(rows):
+        lead = 1.0 + rng.integers(0, 128, size=(rows, k)) / 128.0          # a1: any 8-bit significand in [1, 2)
+        v = (lead + resid).astype(np.float32)
+        assert np.array_equal(v.astype(np.float64), lead + resid)            # exactly representable: the pattern is what is fed
+        return v
+    a, b = operand(m), operand(n)
+    # the split the kernels perform (round to nearest even, three times) leaves residuals of one sign, as intended
+    a1 = _t(a).bfloat16().float().cpu().numpy()
+    a2 = _t(a - a1).bfloat16().float().cpu().numpy()
+    a3 = a - a1 - a2
+    assert (a2 > 0).all() and (a3 > 0).all() and float(a2.min()) > 0.99 * 2.0 ** -8 and float(a3.min()) > 0.49 * 2.0 ** -16
+    ref = a.astype(np.float64) @ b.astype(np.float64).T                       # all terms positive: scale = ref
+    before = ops.gemm_split_mode()
+    err = {}
+    try:
+        for mode in (0, 6, 9):
+            ops.gemm_split_mode(mode)
+            c = ops.gemm(_t(a), _t(b), trans_b=True, split_k=1).cpu().numpy().astype(np.float64)
+            err[mode] = float((np.abs(c - ref) / ref).max())
+    finally:
+        ops.gemm_split_mode(before)
+    assert abs(err[6] - err[9]) <= 2.0 ** -23, err                    # what six products leave out: at most its stated bound
+    assert err[6] <= err[0] + 2.0 ** -24 and err[9] <= err[0] + 2.0 ** -24, err
+    assert err[6] <= 4e-6, err                                        # (1.5e-6 measured; 1.8e-5 with a single accumulator)
+
+
 @pytest.mark.parametrize('gemm_family', [0, 6, 9], indirect=True)
 def test_gemm_exact_on_small_integers(ops, gemm_family):
     """Integer operands whose products and sums fit 24 bits: every family must return the exact result (the split terms
@@ -221,6 +264,31 @@ def test_conv_fwd_bwd(ops, monkeypatch, which, bsz, t_in, wlds):
     if which == 2:
         dx = ops.conv2_dgrad(dy.to(DEV), w.detach().to(DEV), t_in)
         np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), atol=2e-5)
+
+
+def test_conv2_dgrad_workspace_contract(ops, monkeypatch):
+    """ds2_conv2_dgrad takes the SIZE of its workspace (ABI revision 400): with the filter-layout size only it must run the
+    direct kernel -- not write its gather form's zero-bordered copy of d_out past the end -- and with less than that return
+    DS2_ERR_ARG; both answers are the same numbers as with the full workspace."""
+    from ds2hip import lib
+    monkeypatch.setenv('DS2_CONV_SPLIT_DGRAD', '1')                       # the gather form whenever there is room for it
+    torch.manual_seed(2)
+    bsz, t1 = 3, 139
+    dy = torch.randn(bsz, 32, 21, t1 - 10, device=DEV)
+    w = torch.randn(32, 32, 21, 11, device=DEV) / np.sqrt(32 * 21 * 11)
+    full = ops.conv2_dgrad(dy, w, t1)
+    small_n = lib.query('ds2_conv_wt_ws_floats', 2)
+    assert small_n < lib.query('ds2_conv2_dgrad_ws_floats', bsz, t1)
+    guard = 4096
+    ws = torch.full((small_n + guard,), 7.0, device=DEV)
+    d_in = torch.empty(bsz, 32, 61, t1, device=DEV)
+    lib.call('ds2_conv2_dgrad', dy, w, bsz, t1, d_in, ws, small_n)
+    torch.cuda.synchronize()
+    assert bool((ws[small_n:] == 7.0).all()), 'wrote past the workspace it was given'
+    np.testing.assert_allclose(d_in.cpu().numpy(), full.cpu().numpy(), atol=2e-5)
+    with pytest.raises(lib.Ds2Error) as ei:
+        lib.call('ds2_conv2_dgrad', dy, w, bsz, t1, d_in, ws, small_n - 1)
+    assert ei.value.code == lib.ERR_ARG
 
 
 def test_conv2_wgrad_lds_form_repeatable_at_training_size(ops, monkeypatch):
