@@ -1402,17 +1402,21 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
     constexpr bool GIPF = SPEC && DS2_GI_PREFETCH;
     // Staged consumption (validate_fragments), measured round 4 at B = 10 / 8, us per step, all-at-once -> staged -> staged with
     // the loads of successive fragments 2 sleeps apart: FORWARD 2.77 -> 2.73 -> 2.67-2.72 / 2.40 -> 2.30 -> 2.28 (and with the
-    // k-balanced deal 2.64 -> 2.66 -> 2.61 / 2.30 -> 2.30 -> 2.25): on; BACKWARD 2.92 -> 2.97 -> 3.0 / 2.41 -> 2.63 -> 2.50: off
-    // (five validations per step instead of one ballot-free pass cost more than the earlier start of the MFMAs brings).
+    // k-balanced deal 2.64 -> 2.66 -> 2.61 / 2.30 -> 2.30 -> 2.25; 4 sleeps: 2.56 / 2.17): on; BACKWARD, one stage per k group:
+    // 2.92 -> 2.97 -> 3.0 / 2.41 -> 2.63 -> 2.50 (five validations per step cost more than the earlier start of the MFMAs
+    // brings) -- two stages are what pays there (DS2_STAGED_BWD).
 #ifndef DS2_STAGED_FWD
 #define DS2_STAGED_FWD 1
 #endif
 #ifndef DS2_STAGED_BWD
-#define DS2_STAGED_BWD 0
+#define DS2_STAGED_BWD 2         // 0 all at once, 1 one stage per k group, 2 TWO stages (k groups 0-2, then 3-4) -- shipped: with the
+#endif                           // second stage's loads 4-8 sleeps behind the first's, B = 10 / 8 / 12: 2.88 -> 2.86 / 2.39 -> 2.32 / 2.95 -> 2.92
+#ifndef DS2_STAGE_GAP_BWD
+#define DS2_STAGE_GAP_BWD 6      // (swept: 0: 3.13 / 2.55, 4: 2.86 / 2.32, 8: 2.87 / 2.31, 12: 2.92 / 2.40, 16: 3.04 / 2.48 at B = 10 / 8)
 #endif
 #ifndef DS2_STAGE_GAP
-#define DS2_STAGE_GAP 2
-#endif
+#define DS2_STAGE_GAP 4          // (swept round 4, forward, B = 10 / 8 / 12: 2: 2.61 / 2.21 / -, 4: 2.56 / 2.17 / 2.57, 6: 2.58 / 2.16 / 2.58,
+#endif                           //  8: 2.60 / 2.15 / 2.62, 10: 2.66 / 2.16 / 2.65, 14: 2.67 / 2.22 / 2.66)
     constexpr bool STAGED = SPEC && DS2_STAGED_BWD;        // validate + multiply k group by k group (validate_fragments)
     float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
     for (int s = 0; s < T; ++s) {
@@ -1474,7 +1478,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 };
 #pragma unroll
                 for (int gi = 0; gi < NGI; ++gi) {                 // k-group major: the MFMAs below consume in this order
-                    if (STAGED && DS2_STAGE_GAP > 0 && gi > 0) __builtin_amdgcn_s_sleep(DS2_STAGE_GAP);
+                    if (STAGED && DS2_STAGE_GAP_BWD > 0 && (DS2_STAGED_BWD == 2 ? gi == (3 * NGI + 4) / 5 : gi > 0))
+                        __builtin_amdgcn_s_sleep(DS2_STAGE_GAP_BWD);
 #pragma unroll
                     for (int ci = 0; ci < NCI; ++ci) load_frag(ci, gi);
                 }
@@ -1506,18 +1511,24 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 #pragma unroll
                         for (int ci = 0; ci < NCI; ++ci) acc[rg][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
                     bool racc = false;
-                    static_for<0, NGI>([&](auto gi_tag) {
-                        constexpr int gi = decltype(gi_tag)::value;
-                        validate_fragments<NCI, NGI, 0, gi, gi + 1>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync,
-                                                                    abort_flag, nretry, &racc, gi == NGI - 1);
-                        if (gi == 0) DS2_WTICK(3);
+                    // DS2_STAGED_BWD = 1: one stage per k group; 2: two stages (k groups 0 .. SPLIT - 1, then the rest)
+                    constexpr int SPLIT = (3 * NGI + 4) / 5;
+                    constexpr int NSTG = DS2_STAGED_BWD == 2 && NGI > 1 ? 2 : NGI;
+                    static_for<0, NSTG>([&](auto st_tag) {
+                        constexpr int st = decltype(st_tag)::value;
+                        constexpr int G0 = NSTG == NGI ? st : (st == 0 ? 0 : SPLIT), G1 = NSTG == NGI ? st + 1 : (st == 0 ? SPLIT : NGI);
+                        validate_fragments<NCI, NGI, 0, G0, G1>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync,
+                                                                abort_flag, nretry, &racc, st == NSTG - 1);
+                        if (st == 0) DS2_WTICK(3);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int gi = G0; gi < G1; ++gi)
 #pragma unroll
-                            for (int ci = 0; ci < NCI; ++ci)
+                            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                                for (int rg = 0; rg < NRG; ++rg)
-                                    acc[rg][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[rg][gi][e], bf[ci][gi][e], acc[rg][ci], 0, 0, 0);
+                                for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+                                    for (int rg = 0; rg < NRG; ++rg)
+                                        acc[rg][ci] = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[rg][gi][e], bf[ci][gi][e], acc[rg][ci], 0, 0, 0);
                     });
                 } else {
                 if (SPEC) validate_fragments<NCI, NGI>(bf, load_frag, c == 0, spec, spec_delay, spec_clean, sync, abort_flag, nretry);
