@@ -222,6 +222,10 @@ def cpu_baseline(plan, budget_s=60.0, full=True, parity=None):
                     (np.sort(probs, -1)[..., -1] - np.sort(probs, -1)[..., -2])[(parity['argmax'] != probs.argmax(-1)) & valid]),
                 'out_sizes_equal': bool(np.array_equal(parity['out_sizes'], sizes)),
                 'tolerances': 'north_star: logits 1e-3 abs, CTC loss 1e-4 rel, greedy strings identical',
+                'unpinned_third_party': 'the oracle itself is pinned to the reference model (tests/golden/make_golden.py, T up to 746); '
+                                        'what the reference delegates to code absent from its tree stays unpinned: warp-ctc (stand-in: '
+                                        'F.ctc_loss + fp64 path enumeration; the infeasible-utterance rule is a recollection), librosa '
+                                        '(stand-in: torch.stft), torchaudio / sox (amplitude scale and tempo resampling: README.md)',
                 'what': 'HIP path (STFT frontend -> model -> CTC -> backward) against the CPU oracle (oracle/: numpy STFT, '
                         'torch CPU conv/BN/GRU/Linear, F.ctc_loss) on the SAME audio from the SAME weights: the HIP model\'s '
                         'state_dict after this run\'s training steps is loaded into the oracle before its step on this bin'}
