@@ -1586,9 +1586,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         __syncthreads();
         DS2_TICK(4);
         DS2_WTICK(6);
-        // a wave gave up on a payload that never came (bounded re-loads): the flag is READ here, with the partial sums, and
-        // TESTED before anything leaves the workgroup -- its LDS round trip is not a separate stop on the step's chain
-        const int aborted = CAN ? abort_flag : 0;
+        // (a wave that gave up on a payload that never came has raised abort_flag before the barrier above: read behind this
+        // step's hand-off stores, tested at the end of the step -- see the forward kernel)
         if (gate_ok) {
             if (s > 0) {
                 const int rg = jj >> 2, rr = jj & 3, cg = nn >> 2, bj = nn & 3;
@@ -1614,7 +1613,6 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             sv_n = dn_pre;
             sv_g = dn_pre * r;
         }
-        if (aborted) return;
         if (CAN) {
             // Hand-off stores of the speculative protocol: four neighbouring gate threads (units 4q .. 4q+3 of one batch row:
             // adjacent lanes, 16 contiguous bytes of the ring) hand their values to the first of them, which issues ONE
@@ -1653,6 +1651,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                 }
             }
         }
+        const int aborted = CAN ? abort_flag : 0;      // (issued here, consumed at the end of the step)
         if (GIPF && s + 1 < T) early_loads(dir == 0 ? T - 2 - s : s + 1);      // the next step's, behind this step's payload
         DS2_TICK(5);
         if (!CAN && !DS2_DBG(dbg, 4)) wait_vmcnt0();
@@ -1678,6 +1677,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         // polling wave (0) starts polling at once instead and drains after its poll has matched (its stores are old by then).
         if (CAN && !SPEC && wave != SIGW) wait_vmcnt0();
         DS2_WTICK(10);
+        if (aborted) return;
     }
     DS2_RETRY_FLUSH(nretry);
     if (tid == SIGW * 64) leave_kernel(sync);   // the thread whose arrival adds must have been performed first
@@ -2095,10 +2095,17 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         DS2_WTICK(6);
         // a wave gave up on a payload that never came (bounded re-loads): read with the partial sums, tested before the
         // stores (see the backward kernel)
-        const int aborted = CAN ? abort_flag : 0;
+        // (A wave that gave up on a payload that never came -- bounded re-loads -- has raised abort_flag before the barrier
+        // above.  The flag is read behind this step's hand-off stores and tested at the END of the step: read up here, the
+        // compiler made it wave-uniform and waited for its LDS round trip before it issued the partial-sum reads.  A step that
+        // publishes a payload computed from a missing fragment harms nobody: the launch has failed, the sticky error flag is
+        // set, the host raises.)
         // speculative protocol: the previous step's stores (a step old) are complete before this step's payload goes out
         if (SPEC) wait_vmcnt0();
         DS2_WTICK(7);
+        // where this step's payload and the canary two slots ahead go (scalar arithmetic, off the path gate math -> store)
+        float* const pay_slot = my_ring + (size_t)scur * slot_floats;
+        float* const can_slot = my_ring + (size_t)((scur + CAHEAD) % NSLOT) * slot_floats;
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {
             const int lb = bt * RPP + nn;
@@ -2125,18 +2132,18 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
                 const float n = fast_tanh(gi_n[bt] + r * gh_n);
                 const float h = (1.f - z) * n + z * hp[bt];
                 hp[bt] = h;
-                if (gpart == 0 && !aborted) {
+                if (gpart == 0) {
                     // (speculative protocol, fault-injection builds: workgroup 0 'loses' its payload of step 2)
                     const bool lose = SPEC && DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
-                    if (!lose) store_sc1(my_ring + (size_t)scur * slot_floats + hoff[bt], CAN ? not_canary(h) : h);
-                    if (CAN) store_canary(my_ring + (size_t)((scur + CAHEAD) % NSLOT) * slot_floats + hoff[bt]);
+                    if (!lose) store_sc1(pay_slot + hoff[bt], CAN ? not_canary(h) : h);
+                    if (CAN) store_canary(can_slot + hoff[bt]);
                 }
                 sv_h[bt] = h;
                 sv_a[bt] = gpart == 1 ? r : (gpart == 2 ? z : n);
                 sv_g[bt] = gh_n;
             }
         }
-        if (aborted) return;
+        const int aborted = CAN ? abort_flag : 0;      // (issued here, consumed at the end of the step)
         if (GIPF && s + 1 < T) early_loads(dir == 0 ? s + 1 : T - 2 - s);             // the next step's, behind this step's payload
         if (!CAN && !DS2_DBG(dbg, 4)) wait_vmcnt0();   // every storing wave drains its hand-off store
         if (SPEC && (spec & (1 << 17))) wait_vmcnt0();   // self-timed: see spec_timing()
@@ -2166,6 +2173,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
         // wave drains after its poll instead
         if (CAN && !SPEC && wave != 0) wait_vmcnt0();
         DS2_WTICK(10);
+        if (aborted) return;
     }
     DS2_RETRY_FLUSH(nretry);
     if (tid == 0) leave_kernel(sync);
