@@ -691,16 +691,23 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2b_kernel(float*
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
+    // Round 4 (as in the 4x4x1 kernels): the gate pre-activations of step s + 1 are loaded at the END of step s, behind the
+    // saved-activation stores, instead of at the top of step s + 1 in front of its hand-off loads (a wave's vector-memory
+    // operations complete in issue order)
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
+    auto load_gi = [&](int t) {
+        if (gate_ok) {
+            const size_t gb3 = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
+            gi_r = G[gb3];
+            gi_z = G[gb3 + H];
+            gi_n = G[gb3 + 2 * H];
+        }
+    };
+    load_gi(dir == 0 ? 0 : T - 1);
     for (int s = 0; s < T; ++s) {
         const int t = dir == 0 ? s : T - 1 - s;
-        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f, sv_h = 0.f;
-        size_t gbase = 0;
-        if (gate_ok) {                                  // independent of h: issue before the wait
-            gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
-            gi_r = G[gbase];
-            gi_z = G[gbase + H];
-            gi_n = G[gbase + 2 * H];
-        }
+        float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f, sv_h = 0.f;
+        const size_t gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
         if (s > 0) {
             if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
@@ -788,6 +795,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2b_kernel(float*
             G[gbase + 2 * H] = sv_n;
             ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g;
         }
+        if (s + 1 < T) load_gi(dir == 0 ? s + 1 : T - 2 - s);
     }
     if (tid == 0) leave_kernel(sync);
 }
@@ -986,14 +994,14 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2_kernel(float* 
     unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
     __syncthreads();
 
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? T - 1 - s : s;
-        const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
-        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
-        size_t row = 0, gbase = 0;
-        if (gate_ok) {                                  // saved activations of step t: plain loads, issued before the wait
-            row = ((size_t)t * B + gb) * 2 + dir;
-            gbase = row * 3 * H + gj;
+    // Round 4 (as in the 4x4x1 kernels): the saved activations of step s + 1 are loaded at the END of step s, behind the
+    // saved-activation stores, not at the top of step s + 1 in front of its hand-off loads
+    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
+    auto load_saved = [&](int t) {
+        dh = r = z = n = gn = hpv = 0.f;
+        if (gate_ok) {
+            const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
+            const size_t row = ((size_t)t * B + gb) * 2 + dir, gbase = row * 3 * H + gj;
             dh = d_out[((size_t)t * B + gb) * H + gj];
             r = G[gbase];
             z = G[gbase + H];
@@ -1001,6 +1009,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2_kernel(float* 
             gn = ghn[row * H + gj];
             if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
         }
+    };
+    load_saved(dir == 0 ? T - 1 : 0);
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? T - 1 - s : s;
+        float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
+        const size_t row = ((size_t)t * B + gb) * 2 + dir, gbase = row * 3 * H + gj;
         if (s > 0) {
             if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
                 abort_flag = 1;
@@ -1097,6 +1111,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2_kernel(float* 
             G[gbase + 2 * H] = sv_n;
             ghn[row * H + gj] = sv_g;
         }
+        if (s + 1 < T) load_saved(dir == 0 ? T - 2 - s : s + 1);
     }
     if (tid == 0) leave_kernel(sync);
 }
