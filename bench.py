@@ -396,7 +396,8 @@ def timed_steps(step, n, warmup, use_dist):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    gc.collect()                  # (a generation-2 collection inside a 0.3 s timed region is a 5 % outlier; collect now)
+    gc.collect()                  # (a generation-2 collection inside a 0.3 s timed region is a 5 % outlier: collect now, and
+    gc.freeze()                   # keep what exists -- model, bins, modules -- out of the collections the timed steps trigger)
     stamps = []
     t0 = time.time()
     p0 = time.perf_counter()
