@@ -194,9 +194,42 @@ class DeepSpeech(nn.Module):
                 p.data = flat[o:o + p.numel()].view(p.shape)
         self._flat_p, self._plist, self._offsets = flat, order, offsets
         self._flat_g = None
+        self.__dict__['_flat_sig'] = None
         return self
 
+    def _flat_signature(self):
+        """What the fast path of ``_ensure_flat`` checks: every (parent, child name, child) edge of the module tree and, for
+        every parameter of the flat order, (owner module, name, parameter object, offset)."""
+        edges, owners = [], {}
+        for parent in self.modules():
+            for nm, child in parent._modules.items():
+                edges.append((parent, nm, child))
+            for nm, prm in parent._parameters.items():
+                if prm is not None:
+                    owners[id(prm)] = (parent, nm)
+        params = [(owners[id(p)][0], owners[id(p)][1], p, o) for p, o in zip(self._plist, self._offsets)]
+        return edges, params
+
     def _ensure_flat(self):
+        """The parameters are views of ONE flat buffer, in the flat order.  Called at the top of every step, with the GPU idle
+        under the reference's synchronise-per-step protocol, so the common case is cheap (~70 dict lookups and pointer compares:
+        the module tree has its recorded edges, every parameter object is where it was and points where it should); anything
+        else -- ``.to()``, a swapped sub-module (fine-tuning), a re-assigned parameter -- takes the full walk below."""
+        sig = self.__dict__.get('_flat_sig')
+        if sig is not None and self._flat_p is not None:
+            base = self._flat_p.data_ptr()
+            ok = True
+            for parent, nm, child in sig[0]:
+                if parent._modules.get(nm) is not child:
+                    ok = False
+                    break
+            if ok:
+                for owner, nm, p, o in sig[1]:
+                    if owner._parameters.get(nm) is not p or p.data_ptr() != base + 4 * o:
+                        ok = False
+                        break
+            if ok:
+                return
         order = self._flat_order()
         ok = self._flat_p is not None and len(order) == len(self._plist)
         if ok:
@@ -207,6 +240,7 @@ class DeepSpeech(nn.Module):
                     break
         if not ok:
             self.flatten_parameters()
+        self.__dict__['_flat_sig'] = self._flat_signature()
 
     def flat_grad(self):
         """Persistent flat gradient buffer; each parameter's .grad is a view of it."""
@@ -263,13 +297,15 @@ class DeepSpeech(nn.Module):
         sv = {'t_in': t_in, 't1': t1, 't': t, 'bsz': bsz}
         c = self.conv
         # fine-tuning with frozen conv layers keeps their BatchNorm in inference mode (training_utils.py:52-54,73)
-        conv_frozen = getattr(c[1], 'frozen_stats', False) or getattr(c[4], 'frozen_stats', False)
+        # (plain instance-dict lookups: a missing attribute on an nn.Module costs a failed walk through its parameter /
+        # buffer / sub-module tables and an exception -- ~3 us each, ~30 of them here, at the top of a step with the GPU idle)
+        conv_frozen = c[1].__dict__.get('frozen_stats', False) or c[4].__dict__.get('frozen_stats', False)
         conv_train = training and not conv_frozen
         mods = self.__dict__.get('_bn_walk')
         if mods is None:                                   # the module tree is static: walk it once
             mods = self.__dict__['_bn_walk'] = list(self.rnns.modules()) + list(self.fc.modules())
         for mod in mods:
-            if getattr(mod, 'frozen_stats', False):
+            if mod.__dict__.get('frozen_stats', False):
                 raise NotImplementedError('freezing BatchNorm statistics is supported for the conv block only')
         self._tick('start')
         xt = ops.transpose_btf(x)                                                   # (B,161,T_in)

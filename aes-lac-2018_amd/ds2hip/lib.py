@@ -114,7 +114,17 @@ def _ptr(x):
     return x
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream_ptr():
+    """The raw HIP stream torch considers current on the current device.  ``torch.cuda.current_stream().cuda_stream`` builds
+    a Stream object and resolves the device index through three Python layers (~8 us; ~100 calls per training step, the
+    first dozen of them with the GPU idle under the synchronise-per-step protocol); the two C entry points below are what it
+    ends up calling."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -127,7 +137,7 @@ def call(name, *args):
     if fn is None:
         fn = _fn_cache[name] = getattr(load(), name)
     rc = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) and a.is_cuda and a.is_contiguous() else _ptr(a)
-              for a in args], torch.cuda.current_stream().cuda_stream)
+              for a in args], stream_ptr())
     if rc != 0:
         raise Ds2Error(rc, '%s failed (%d): %s' % (name, rc, load().ds2_last_error().decode()))
 

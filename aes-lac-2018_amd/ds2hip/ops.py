@@ -245,7 +245,7 @@ def gemm_tn_group(problems, n, k, accumulate=False):
     args = (vp(*a), ip(*lda), ip(*m), vp(*b), ip(*ldb), vp(*c), ip(*ldc))
     fn = lib.load().ds2_gemm_f32_tn_group
     rc = fn(cnt, *[ctypes.cast(x, ctypes.c_void_p) for x in args], int(n), int(k), int(bool(accumulate)),
-            torch.cuda.current_stream().cuda_stream)
+            lib.stream_ptr())
     if rc != 0:
         raise lib.Ds2Error(rc, 'ds2_gemm_f32_tn_group failed (%d): %s' % (rc, lib.load().ds2_last_error().decode()))
 
