@@ -405,3 +405,32 @@ def test_data_parallel_env_is_one_function_for_train_and_bench():
         src = open(os.path.join(root, name)).read()
         assert 'data_parallel_env()' in src, name
         assert "setdefault('NCCL_MAX_NCHANNELS'" not in src and "setdefault('GPU_MAX_HW_QUEUES'" not in src, name
+
+
+@pytest.mark.parametrize('world', [1, 2, 4, 8])
+def test_bench_bin_plan_is_the_reference_partition(world):
+    """bench.py's synthetic corpus under N ranks: rank r times bins r, r + N, ... of the plan (codes/sampler.py:119-125's rule);
+    the N bins of one step are ADJACENT in the length-sorted corpus (similar lengths: the step's max over ranks is not set by a
+    straggler), every rank sees the same number of bins, the ranks' bins tile the corpus exactly once, and any window of
+    consecutive steps has about the corpus's mean clip length (the short / long interleave)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    plan = bench.bin_plan(10, bench.NUM_BINS * world, world=world)
+    assert len(plan) == bench.NUM_BINS * world
+    seeds = [p[0] for p in plan]
+    assert len(set(seeds)) == len(seeds)                               # every bin of the corpus exactly once
+    per_rank = [plan[r::world] for r in range(world)]
+    assert all(len(b) == bench.NUM_BINS for b in per_rank)
+    means = np.array([[float(np.mean(e[1])) for e in b] for b in per_rank])      # [rank][step] mean clip seconds
+    spread = (means.max(0) - means.min(0)) / means.mean(0)
+    # one step's bins have similar lengths: N adjacent bins span N x 0.07 s of the corpus -- 6 % of the mean clip for the
+    # median step at N = 8, 44 % for the very shortest group (1.0 .. 1.6 s clips), whose step is the cheapest anyway
+    assert float(spread.max()) < 0.5 and float(np.median(spread)) < 0.08, spread
+    frames = np.array([[bench.frames_of_plan(e) for e in b] for b in per_rank]).sum(0)
+    win = np.convolve(frames, np.ones(4) / 4.0, mode='valid')
+    assert float(win.max() / win.min()) < 1.6                           # any four consecutive steps: about the mean length
+    for e in plan:
+        assert np.all(np.diff(e[1]) >= 0) and 1.0 <= e[1][0] and e[1][-1] <= 15.0
