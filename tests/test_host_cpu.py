@@ -135,3 +135,31 @@ def test_decoder_distances_match_oracle():
     assert tgt == [['AAB']]                                   # no repetition removal for targets
     got = dec.convert_to_strings([torch.tensor([2, 2, 0, 3])], remove_repetitions=True, return_offsets=True)
     assert got[0] == [['AB']] and got[1][0][0].tolist() == [0, 3]
+
+
+def test_flat_parameter_check_fast_path_still_sees_every_change():
+    """``DeepSpeech._ensure_flat`` runs at the top of every training step; its fast path (recorded module-tree edges, parameter
+    identity, data pointers) must still notice what the full walk notices: a swapped sub-module (the fine-tune FC surgery), a
+    re-assigned parameter tensor, a moved / re-created flat buffer -- and must not re-pack when nothing changed."""
+    from codes.model import DeepSpeech, _LinearParams
+    m = DeepSpeech(rnn_hidden_size=32, num_rnn_layers=2)
+    m.flatten_parameters()
+    m._ensure_flat()
+    flat = m._flat_p
+    for _ in range(3):
+        m._ensure_flat()
+        assert m._flat_p is flat                                       # unchanged model: no re-pack
+    head = m.fc[0].module
+    head[1] = _LinearParams(32, 43)                                    # codes/utils/training_utils.py:100-104
+    m._ensure_flat()
+    assert m._flat_p is not flat
+    assert head[1].weight.data_ptr() == m._flat_p.data_ptr() + 4 * m._offsets[-1]
+    flat = m._flat_p
+    m.conv[0].weight.data = torch.zeros_like(m.conv[0].weight)         # a parameter pointed somewhere else
+    m._ensure_flat()
+    assert m._flat_p is not flat and m.conv[0].weight.data_ptr() == m._flat_p.data_ptr()
+    flat = m._flat_p
+    m.rnns[1].rnn.weight_hh_l0 = torch.nn.Parameter(torch.ones(96, 32))   # a parameter OBJECT replaced
+    m._ensure_flat()
+    assert m._flat_p is not flat and float(m.rnns[1].rnn.weight_hh_l0.sum()) == 96 * 32
+    assert all(p.data_ptr() == m._flat_p.data_ptr() + 4 * o for p, o in zip(m._plist, m._offsets))
