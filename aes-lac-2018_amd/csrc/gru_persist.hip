@@ -1434,30 +1434,42 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 #endif                           //  8: 2.60 / 2.15 / 2.62, 10: 2.66 / 2.16 / 2.65, 14: 2.67 / 2.22 / 2.66)
     constexpr bool STAGED = SPEC && DS2_STAGED_BWD;        // validate + multiply k group by k group (validate_fragments)
     float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
+    // Running element offsets of this gate thread's saved activations: every array is affine in the time step, and the step
+    // moves by tstep = -1 (direction 0 walks t = T - 1 .. 0) or + 1, so an offset advances by a CONSTANT per step -- four 64-bit
+    // adds instead of the ~30 vector instructions of 64-bit multiplies the index expressions compiled to, on the two gate
+    // waves, between a step's hand-off stores and its end-of-step barrier.
+    const long long tstep = dir == 0 ? -1 : 1;
+    const long long dG = tstep * B * 6 * H, dD = tstep * B * H, dN = tstep * B * 2 * H;
+    const int t_first = dir == 0 ? T - 1 : 0;
+    size_t of_g = (((size_t)t_first * B + gb) * 2 + dir) * 3 * H + gj;            // G[of_g + g H]: gate g of step t
+    size_t of_d = ((size_t)t_first * B + gb) * H + gj;                            // d_out
+    size_t of_n = (((size_t)t_first * B + gb) * 2 + dir) * H + gj;                // ghn
+    size_t of_h = (((size_t)dir * T + t_first + tstep) * B + gb) * H + gj;        // hout of the step BEFORE t in forward time order
     for (int s = 0; s < T; ++s) {
         DS2_TICK(0);
         const int t = dir == 0 ? T - 1 - s : s;
         float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
-        const size_t row = ((size_t)t * B + gb) * 2 + dir, gbase = row * 3 * H + gj;     // (of the CURRENT step: saved stores)
-        auto early_loads = [&](int t) {
+        // next != 0: the step after this one (its offsets = this step's + the constant strides)
+        auto early_loads = [&](int next) {
             dh = r = z = n = gn = hpv = 0.f;
             if (gate_ok) {
-                // saved activations of step t (written by the forward pass, an earlier launch): plain loads
-                const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
-                const size_t row = ((size_t)t * B + gb) * 2 + dir, gbase = row * 3 * H + gj;
-                dh = d_out[((size_t)t * B + gb) * H + gj];
-                r = G[gbase];
-                z = G[gbase + H];
-                n = G[gbase + 2 * H];
-                gn = ghn[row * H + gj];
-                if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
+                // saved activations (written by the forward pass, an earlier launch): plain loads
+                const int tt = t + (next ? (int)tstep : 0);
+                const bool has_prev = dir == 0 ? (tt > 0) : (tt < T - 1);
+                const size_t g0 = of_g + (next ? dG : 0);
+                dh = d_out[of_d + (next ? dD : 0)];
+                r = G[g0];
+                z = G[g0 + H];
+                n = G[g0 + 2 * H];
+                gn = ghn[of_n + (next ? dN : 0)];
+                if (has_prev) hpv = hout[of_h + (next ? dD : 0)];
             }
         };
         // signal-first: the polling wave polls FIRST, then waits for its own (by then old) stores, and only then issues
         // these loads -- a vmcnt wait behind freshly issued HBM loads would put their latency on the step's chain
         const bool poll_first = CAN && !SPEC && wave == SIGW && s > 0;
         DS2_WTICK(0);
-        if (!poll_first && !(GIPF && s > 0)) early_loads(t);
+        if (!poll_first && !(GIPF && s > 0)) early_loads(0);
         DS2_WTICK(1);
         if (s > 0) {
             if (!SPEC) {
@@ -1465,7 +1477,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
                     abort_flag = 1;
                 if (poll_first) {
                     wait_vmcnt0();   // the polling wave's deferred drain
-                    early_loads(t);
+                    early_loads(0);
                 }
                 DS2_TICK(1);
                 __syncthreads();
@@ -1667,7 +1679,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
             }
         }
         const int aborted = CAN ? abort_flag : 0;      // (issued here, consumed at the end of the step)
-        if (GIPF && s + 1 < T) early_loads(dir == 0 ? T - 2 - s : s + 1);      // the next step's, behind this step's payload
+        if (GIPF && s + 1 < T) early_loads(1);                                 // the next step's, behind this step's payload
         DS2_TICK(5);
         if (!CAN && !DS2_DBG(dbg, 4)) wait_vmcnt0();
         if (SPEC && (spec & (1 << 17))) wait_vmcnt0();   // self-timed: see spec_timing()
@@ -1682,11 +1694,15 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
         if (!SPEC && tid == SIGW * 64 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
             __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
-            G[gbase] = sv_r;
-            G[gbase + H] = sv_z;
-            G[gbase + 2 * H] = sv_n;
-            ghn[row * H + gj] = sv_g;
+            G[of_g] = sv_r;
+            G[of_g + H] = sv_z;
+            G[of_g + 2 * H] = sv_n;
+            ghn[of_n] = sv_g;
         }
+        of_g += dG;
+        of_d += dD;
+        of_n += dN;
+        of_h += dD;
         // the drain, AFTER the signal: this step's stores (payload, next slot's canaries) are complete before the next
         // step's arrival add -- and before its early loads are issued, so the wait never covers a fresh HBM load.  The
         // polling wave (0) starts polling at once instead and drains after its poll has matched (its stores are old by then).
