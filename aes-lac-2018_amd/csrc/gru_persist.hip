@@ -2616,7 +2616,9 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
         else ok = two ? DS2_FWD4_GO(3, 2) : DS2_FWD4_GO(3, 1);
 #undef DS2_FWD4_GO
     }
-    else if ((getenv("DS2_GRU_FWD_P2") ? getenv("DS2_GRU_FWD_P2")[0] == '1' : B >= 17) && B >= 2 && H % 16 == 0)
+    // (round 4, us per step at H = 800: the split-operand two-part form costs 3.32-3.36 whatever B <= 32 is; the whole-batch
+    // 16x16x4 form 3.63 at B = 16 -- so the split form takes over as soon as the 4x4x1 forms end, at B = 13)
+    else if ((getenv("DS2_GRU_FWD_P2") ? getenv("DS2_GRU_FWD_P2")[0] == '1' : B >= (p2_bf16(H) ? 13 : 17)) && B >= 2 && H % 16 == 0)
         ok = p2_bf16(H) ? ((B + 1) / 2 <= 16 ? launch_fwd_persistent_p2b<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
                                              : launch_fwd_persistent_p2b<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
                         : ((B + 1) / 2 <= 16 ? launch_fwd_persistent_p2<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)

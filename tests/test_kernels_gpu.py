@@ -515,12 +515,13 @@ def _long_sequence_case(ops, monkeypatch, bsz, reps, during=None):
     assert not ops._persistent_off                      # no launch fell back to the per-step kernels
 
 
-@pytest.mark.parametrize('bsz', [4, 8, 10, 12, 17, 32, 64])
+@pytest.mark.parametrize('bsz', [4, 8, 10, 12, 13, 16, 17, 32, 64])
 def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch, bsz):
     """T = 746 steps of the real layer shape, repeatedly: every hand-off must be fresh (a stale h would show up as an O(1)
     difference), and the bounded spins must never trip.  The batch sizes cover every hand-off protocol and kernel form:
     4 (speculative, one part), 8 (speculative, two parts), 10 (speculative, three parts: the headline), 12 (the last batch
-    size of the speculative protocol), 17 (the first of the two-part 16x16x4 forms, counted protocol), 32 and 64."""
+    size of the speculative protocol), 13 and 16 (forward: the first of the two-part split-operand forms; backward: the 4x4x1
+    forms with the counted protocol), 17 (the first of the two-part 16x16x4 backward forms), 32 and 64."""
     _long_sequence_case(ops, monkeypatch, bsz, 3 if bsz <= 12 else 2)
 
 
