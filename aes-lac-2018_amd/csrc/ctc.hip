@@ -18,7 +18,6 @@
 
 namespace {
 
-constexpr int CTC_THREADS = 256;
 constexpr int MAX_S = 1024;  // 2*L+1 <= 1024
 #define NEG_INF_D (-(double)INFINITY)
 
@@ -55,23 +54,34 @@ __global__ __launch_bounds__(256) void ctc_lse_kernel(const float* __restrict__ 
     if (lane == 0) lse[row] = mx + logf(s);
 }
 
-// NS = states per thread (ceil(smax / 256), 1 .. 4): a template parameter so that a minibatch of short transcripts does not
-// carry the dead iterations of the longest supported one on the recursion's critical path
-template <int NS>
-__global__ __launch_bounds__(CTC_THREADS) void ctc_alphabeta_kernel(
+// One state per thread: NTHR = 256 / 512 / 1024 threads for up to that many states (2 L + 1 of the longest transcript of the
+// minibatch), so a minibatch of short transcripts does not pay the barrier of sixteen waves.
+//
+// Emissions.  State s of frame t needs acts[t][b][ext[s]] - lse[t][b].  Fetched per frame they put a global-memory round
+// trip on every step of the recursion (round 1-3: a "prefetch" whose subtraction made the compiler wait for it at once, and a
+// vmcnt(0) that also covered the previous frame's alpha / beta store: 0.47 us per frame, 185 us for T = 391).  Now whole
+// frames are staged through LDS, CH at a time: the loads of chunk c + 1 are issued before chunk c's first frame and land in
+// the other LDS buffer at its last one -- one memory wait per CH frames, and a frame is LDS reads -> log-sum-exp -> LDS write
+// -> barrier.
+constexpr int EM_FLOATS = 1024;          // per buffer: CH = min(32, 1024 / A) frames (A = 29: 32, A = 43: 23, A = 256: 4)
+constexpr int EM_NLD = 4;                // staging loads per thread and chunk (256 threads do the staging)
+
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void ctc_alphabeta_kernel(
     const float* __restrict__ acts, const float* __restrict__ lse, const int32_t* __restrict__ labels,
     const int32_t* __restrict__ label_offsets, const int32_t* __restrict__ label_lens,
     const int32_t* __restrict__ act_lens, int T, int B, int A, int smax, double* __restrict__ alpha,
     double* __restrict__ beta, double* __restrict__ ll_out, float* __restrict__ costs) {
     __shared__ int ext[MAX_S];
     __shared__ double rowbuf[2][MAX_S + 4];
+    __shared__ float em[2][EM_FLOATS];
 
     const int b = blockIdx.x, dirn = blockIdx.y, tid = threadIdx.x;
     const int L = label_lens[b], tl = min(act_lens[b], T);
     const int S = 2 * L + 1;
     const int32_t* lab = labels + label_offsets[b];
-    for (int s = tid; s < S; s += CTC_THREADS) ext[s] = (s & 1) ? lab[s >> 1] : 0;
-    for (int i = tid; i < MAX_S + 4; i += CTC_THREADS) {
+    for (int s = tid; s < S; s += NTHR) ext[s] = (s & 1) ? lab[s >> 1] : 0;
+    for (int i = tid; i < MAX_S + 4; i += NTHR) {
         rowbuf[0][i] = NEG_INF_D;
         rowbuf[1][i] = NEG_INF_D;
     }
@@ -85,89 +95,84 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_alphabeta_kernel(
         return;
     }
     double* out = (dirn == 0 ? alpha : beta) + (size_t)b * T * smax;
-    int sym[NS];
-    bool skip[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int s = tid + i * CTC_THREADS;
-        sym[i] = s < S ? ext[s] : 0;
-        if (dirn == 0)
-            skip[i] = (s < S) && (s >= 2) && (ext[s] != 0) && (ext[s] != ext[s - 2]);
-        else
-            skip[i] = (s + 2 < S) && (ext[s] != 0) && (ext[s] != ext[s + 2]);
-    }
+    const int s = tid;
+    const bool live = s < S;
+    const int sym = live ? ext[s] : 0;
+    const bool skip = dirn == 0 ? (live && (s >= 2) && (ext[s] != 0) && (ext[s] != ext[s - 2]))
+                                : ((s + 2 < S) && (ext[s] != 0) && (ext[s] != ext[s + 2]));
     // rowbuf[.][s + 1] holds state s; cells 0 and S+1.. stay -inf guards
+    const int i1 = dirn == 0 ? s : s + 2, i2 = dirn == 0 ? max(s - 1, 0) : s + 3;     // cells of the two other predecessors
     const int tstart = dirn == 0 ? 0 : tl - 1;
     const int tstep = dirn == 0 ? 1 : -1;
-    {
+    if (live) {
         const float* arow = acts + ((size_t)tstart * B + b) * A;
         const float l0 = lse[(size_t)tstart * B + b];
+        const bool on = dirn == 0 ? (s <= 1) : (s >= S - 2);
+        const double v = on ? (double)(arow[sym] - l0) : NEG_INF_D;
+        rowbuf[0][s + 1] = v;
+        out[(size_t)tstart * smax + s] = v;
+    }
+    // staging roles: thread tid < 256 carries elements idx = tid + 256 i of a chunk, idx = f A + k (frame f of the chunk, symbol k)
+    const int CH = min(32, EM_FLOATS / A), nper = CH * A;
+    const int nsteps = tl - 1;                          // recursion steps 1 .. tl - 1; step n works on frame tstart + tstep n
+    const int nchunk = (nsteps + CH - 1) / CH;
+    int st_f[EM_NLD], st_k[EM_NLD];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int s = tid + i * CTC_THREADS;
-            if (s < S) {
-                const bool on = dirn == 0 ? (s <= 1) : (s >= S - 2);
-                const double v = on ? (double)(arow[sym[i]] - l0) : NEG_INF_D;
-                rowbuf[0][s + 1] = v;
-                out[(size_t)tstart * smax + s] = v;
+    for (int i = 0; i < EM_NLD; ++i) {
+        const int idx = tid + 256 * i;
+        st_f[i] = (tid < 256 && idx < nper) ? idx / A : -1;
+        st_k[i] = idx - (idx / A) * A;
+    }
+    float ra[EM_NLD], rl[EM_NLD];
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < EM_NLD; ++i) {
+            ra[i] = rl[i] = 0.f;
+            const int n = 1 + c * CH + st_f[i];
+            if (st_f[i] >= 0 && n < tl) {
+                const size_t row = (size_t)(tstart + tstep * n) * B + b;
+                ra[i] = acts[row * A + st_k[i]];
+                rl[i] = lse[row];
             }
         }
+    };
+    auto stage_store = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < EM_NLD; ++i)
+            if (st_f[i] >= 0) {
+                float a = ra[i];
+                asm volatile("" : "+v"(a));      // keeps the subtraction (and with it the wait for the loads) HERE, at the chunk's
+                dst[tid + 256 * i] = a - rl[i];  // last frame: hoisted in front of the frame loop it would wait at the chunk's first
+            }
+    };
+    if (nchunk > 0) {
+        stage_load(0);
+        stage_store(em[0]);
     }
     __syncthreads();
     int cur = 0;
-    int t = tstart + tstep;
-    float lp[NS];
-    if (tl > 1) {
-        const float* arow = acts + ((size_t)t * B + b) * A;
-        const float l0 = lse[(size_t)t * B + b];
-#pragma unroll
-        for (int i = 0; i < NS; ++i) lp[i] = (tid + i * CTC_THREADS < S) ? arow[sym[i]] - l0 : 0.f;
-    }
-    for (int step = 1; step < tl; ++step) {
-        const double* prev = rowbuf[cur];
-        double* nxt = rowbuf[cur ^ 1];
-        double val[NS];
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int s = tid + i * CTC_THREADS;
-            val[i] = NEG_INF_D;
-            if (s < S) {
-                const double x0 = prev[s + 1];
-                double x1, x2 = NEG_INF_D;
-                if (dirn == 0) {
-                    x1 = prev[s];
-                    if (skip[i]) x2 = prev[s - 1];
-                } else {
-                    x1 = prev[s + 2];
-                    if (skip[i]) x2 = prev[s + 3];
-                }
-                val[i] = lse3m(x0, x1, x2) + (double)lp[i];
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;
+        if (more) stage_load(c + 1);                    // in flight while this chunk's frames are worked on
+        const float* e = em[c & 1] + sym;
+        const int fend = min(CH, nsteps - c * CH);
+        int t = tstart + tstep * (1 + c * CH);
+        for (int f = 0; f < fend; ++f) {
+            const double* prev = rowbuf[cur];
+            double* nxt = rowbuf[cur ^ 1];
+            if (live) {
+                // all four LDS reads go out together (the third predecessor is read whether it counts or not)
+                const double x0 = prev[s + 1], x1 = prev[i1], x2r = prev[i2];
+                const float ev = e[f * A];
+                const double val = lse3m(x0, x1, skip ? x2r : NEG_INF_D) + (double)ev;
+                nxt[s + 1] = val;
+                out[(size_t)t * smax + s] = val;
             }
+            if (more && f == fend - 1) stage_store(em[(c + 1) & 1]);    // (its last readers passed chunk c - 1's final barrier)
+            __syncthreads();
+            cur ^= 1;
+            t += tstep;
         }
-        const int tn = t + tstep;
-        float lpn[NS];
-        if (step + 1 < tl) {  // prefetch next frame's emissions before the barrier
-            const float* arow = acts + ((size_t)tn * B + b) * A;
-            const float l0 = lse[(size_t)tn * B + b];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) lpn[i] = (tid + i * CTC_THREADS < S) ? arow[sym[i]] - l0 : 0.f;
-        } else {
-#pragma unroll
-            for (int i = 0; i < NS; ++i) lpn[i] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int s = tid + i * CTC_THREADS;
-            if (s < S) {
-                nxt[s + 1] = val[i];
-                out[(size_t)t * smax + s] = val[i];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NS; ++i) lp[i] = lpn[i];
-        cur ^= 1;
-        t = tn;
     }
     if (dirn == 0 && tid == 0) {
         const double* last = rowbuf[cur];
@@ -254,14 +259,11 @@ extern "C" int ds2_ctc_loss_grad(const float* acts, const int32_t* labels, const
     float* lse = (float*)(ll + B);
     hipLaunchKernelGGL(ctc_lse_kernel, dim3(ds2_cdiv((long)T * B, 4)), dim3(256), 0, st, acts, T * B, A, lse);
 #define DS2_CTC_AB(N_)                                                                                                  \
-    hipLaunchKernelGGL(ctc_alphabeta_kernel<N_>, dim3(B, 2), dim3(CTC_THREADS), 0, st, acts, lse, labels, label_offsets,  \
+    hipLaunchKernelGGL(ctc_alphabeta_kernel<N_>, dim3(B, 2), dim3(N_), 0, st, acts, lse, labels, label_offsets,          \
                        label_lens, act_lens, T, B, A, smax, alpha, beta, ll, costs)
-    switch (ds2_cdiv(smax, CTC_THREADS)) {
-        case 1: DS2_CTC_AB(1); break;
-        case 2: DS2_CTC_AB(2); break;
-        case 3: DS2_CTC_AB(3); break;
-        default: DS2_CTC_AB(4); break;
-    }
+    if (smax <= 256) DS2_CTC_AB(256);
+    else if (smax <= 512) DS2_CTC_AB(512);
+    else DS2_CTC_AB(1024);
 #undef DS2_CTC_AB
     hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(128), 0, st, acts, lse, labels, label_offsets, label_lens,
                        act_lens, T, B, A, smax, alpha, beta, ll, grad_scale, zero_batch_if_inf, grad);

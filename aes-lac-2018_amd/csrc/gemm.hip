@@ -768,19 +768,25 @@ __device__ __forceinline__ void gemm_split_tile_body(char (&lds)[2][2][SPLIT_TIL
         constexpr int cur = decltype(PAR)::value;                        // s & 1: LDS buffer and register set of slab s
         // (unconditional: past the last slab the loads fetch zeros or data nobody uses -- under a condition the compiler's
         // wait-count insertion has to assume they were NOT issued and waits for them together with slab s + 1's)
+        if (!(DS2_GEMM_ABL & 2)) {
         split_load<A_KCONTIG>(rsa, va, lda, kbeg + (s + 2) * BK, ra[cur]);
         split_load<B_KCONTIG>(rsb, vb, ldb, kbeg + (s + 2) * BK, rb[cur]);
+        }
         const char* as = lds[cur][0] + a_off;
         const char* bs = lds[cur][1] + b_off;
         bf16x8 a[NI_][3], b[NJ_][3];
 #pragma unroll
         for (int i = 0; i < NI_; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(as + i * 32 * SP + q * 32);
+            for (int q = 0; q < 3; ++q)
+                a[i][q] = (DS2_GEMM_ABL & 4) ? __builtin_bit_cast(bf16x8, f32x4{ra[0][0] + q, ra[0][1], ra[0][2], ra[0][3] + i})
+                                             : *reinterpret_cast<const bf16x8*>(as + i * 32 * SP + q * 32);
 #pragma unroll
         for (int j = 0; j < NJ_; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * SP + q * 32);
+            for (int q = 0; q < 3; ++q)
+                b[j][q] = (DS2_GEMM_ABL & 4) ? __builtin_bit_cast(bf16x8, f32x4{rb[0][0] + q, rb[0][1], rb[0][2], rb[0][3] + j})
+                                             : *reinterpret_cast<const bf16x8*>(bs + j * 32 * SP + q * 32);
 #pragma unroll
         for (int i = 0; i < NI_; ++i)
 #pragma unroll
@@ -788,8 +794,10 @@ __device__ __forceinline__ void gemm_split_tile_body(char (&lds)[2][2][SPLIT_TIL
                 split_mfma2<NPROD>(a[i], b[j], acc[i][j], acc_lo[i][j]);
             }
         // (unconditional as well: behind the last slab it fills a buffer nobody reads)
+        if (!(DS2_GEMM_ABL & 1)) {
         split_store<A_KCONTIG>(lds[cur ^ 1][0], tid, ra[cur ^ 1]);
         split_store<B_KCONTIG>(lds[cur ^ 1][1], tid, rb[cur ^ 1]);
+        }
         // issue order: the compiler puts the 88 vector instructions of the split behind the last MFMA; spread them (and the
         // LDS stores) between the MFMAs, whose issue takes 8 of their 32 pipe cycles
         constexpr int NMFMA = NI_ * NJ_ * NPROD, VPM = (96 + NMFMA - 1) / NMFMA, WEVERY = NMFMA >= 8 ? NMFMA / 8 : 1;

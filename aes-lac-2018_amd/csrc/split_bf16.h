@@ -22,6 +22,12 @@ __device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
 }
 // two fp32 values -> three dwords of packed bf16 pairs (planes 1, 2, 3)
 __device__ __forceinline__ void split3(float a, float b, unsigned int& p1, unsigned int& p2, unsigned int& p3) {
+#if defined(DS2_GEMM_ABL) && (DS2_GEMM_ABL & 16)          // timing-only ablation (results WRONG): no split arithmetic
+    p1 = __builtin_bit_cast(unsigned int, a);
+    p2 = __builtin_bit_cast(unsigned int, b);
+    p3 = p1 ^ p2;
+    return;
+#endif
     p1 = pack_bf16(a, b);
     float ra = a - __builtin_bit_cast(float, p1 << 16), rb = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
     p2 = pack_bf16(ra, rb);
@@ -38,6 +44,11 @@ __device__ __forceinline__ void split3(float a, float b, unsigned int& p1, unsig
 // them; the two accumulators are added once, in the epilogue.  Same MFMA count, two independent chains.
 template <int NPROD>
 __device__ __forceinline__ void split_mfma2(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& hi, f32x16& lo) {
+#if defined(DS2_GEMM_ABL) && (DS2_GEMM_ABL & 8)           // timing-only ablation (results WRONG): one product of the six
+    hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], lo, 0, 0, 0);
+    return;
+#endif
     if (NPROD == 9) {
         lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[2], lo, 0, 0, 0);
         lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], lo, 0, 0, 0);

@@ -642,6 +642,15 @@ def test_ctc_infeasible_and_long(ops):
     costs, grad, rc, rg = _ctc_case(ops, 746, 2, 29, [200, 150], [746, 700], seed=9)
     np.testing.assert_allclose(costs, rc, rtol=1e-4)
     np.testing.assert_allclose(grad, rg, atol=5e-5)
+    # S = 601 states: the 1024-thread form; utterance lengths around the 32-frame staging chunks of the emissions (1 frame, one
+    # chunk exactly, one chunk + 1, two chunks - 1), a one-label and an empty transcript, 43 symbols (23-frame chunks)
+    costs, grad, rc, rg = _ctc_case(ops, 700, 3, 29, [300, 260, 1], [700, 655, 1], seed=10)
+    np.testing.assert_allclose(costs, rc, rtol=1e-4)
+    np.testing.assert_allclose(grad, rg, atol=5e-5)
+    for nalpha, lens in ((29, [33, 34, 63, 2]), (43, [24, 25, 46, 47])):
+        costs, grad, rc, rg = _ctc_case(ops, 64, 4, nalpha, [5, 0, 9, 1], lens, seed=11)
+        np.testing.assert_allclose(costs, rc, rtol=1e-4)
+        np.testing.assert_allclose(grad, rg, atol=2e-5)
 
 
 # ------------------------------------------------------------------------------------------- optimiser
