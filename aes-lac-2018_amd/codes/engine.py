@@ -230,15 +230,22 @@ class Trainer(object):
         # ONE fill of the whole flat gradient, on the side stream beside the forward pass (the step's first side-stream work:
         # everything the backward pass puts there, and the main stream through the w_hh_t_ready event, is ordered behind
         # it), instead of a fill in front of every split-K weight-gradient GEMM
-        main = torch.cuda.current_stream()
-        side = m._side_stream(gflat.device) if m.overlap_wgrad else None
-        if side is not None:
-            side.wait_stream(main)
         prezero = os.environ.get('DS2_PREZERO', '1') != '0'
-        if prezero:
-            with torch.cuda.stream(side if side is not None else main):
-                gflat.zero_()
-        acts, sv = m._forward_impl(inputs.contiguous().float(), training=True, need_grad=True)
+
+        def fill():
+            # (issued by the forward pass right BEHIND its conv-block launches, not in front of them: after a step that ended
+            # with a synchronisation the GPU idles until the first long kernel is enqueued, and the stream switch + fill cost
+            # the host ~25 us there.  Still ahead of everything that writes the gradient: the side stream's own work follows
+            # it in stream order, the main stream's through the w_hh_t_ready event recorded after it.)
+            main = torch.cuda.current_stream()
+            side = m._side_stream(gflat.device) if m.overlap_wgrad else None
+            if side is not None:
+                side.wait_stream(main)
+            if prezero:
+                with torch.cuda.stream(side if side is not None else main):
+                    gflat.zero_()
+
+        acts, sv = m._forward_impl(inputs.contiguous().float(), training=True, need_grad=True, after_conv=fill)
         costs, d_acts = loss_fn(acts)
         m._backward_impl(sv, d_acts, gflat, grad_ready=hook, prezeroed=prezero)
         return costs, acts

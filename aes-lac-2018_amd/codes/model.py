@@ -287,8 +287,9 @@ class DeepSpeech(nn.Module):
             out = ops.softmax_rows(acts.view(t * b, a), t * b, a).view(t, b, a).transpose(0, 1)
         return out
 
-    def _forward_impl(self, x, training, need_grad):
-        """x (B,T_in,161) -> acts (T,B,A); returns the tensors backward needs."""
+    def _forward_impl(self, x, training, need_grad, after_conv=None):
+        """x (B,T_in,161) -> acts (T,B,A); returns the tensors backward needs.  ``after_conv``: called once the conv block's
+        launches are enqueued (the trainer's gradient fill: host work that need not sit in front of the step's first kernels)."""
         bsz, t_in, nfreq = x.shape
         assert nfreq == 161, 'expected 161 frequency bins'
         hid, nlayers = self._rnn_hidden_size, self._num_rnn_layers
@@ -321,6 +322,8 @@ class DeepSpeech(nn.Module):
         sv['conv_frozen'] = conv_frozen
         sv.update(xt=xt, y1=y1, mi1=mi1, a1=a1, y2=y2, mi2=mi2)
         self._tick('conv block forward (transpose, conv1, conv2, 2 x BatchNorm + clip)')
+        if after_conv is not None:
+            after_conv()
         rows = t * bsz
         layers = []
         prev_h = None

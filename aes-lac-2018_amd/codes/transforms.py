@@ -74,8 +74,10 @@ class BatchSpectrogram(object):
             lens = [int(w.numel()) for w in wavs]
             flat = torch.cat([w.reshape(-1).to(self.device, torch.float32) for w in wavs])
         else:
-            flat = wavs.to(self.device, torch.float32).contiguous()
-            lens = [int(offsets[i + 1] - offsets[i]) for i in range(len(offsets) - 1)]
+            flat = wavs if (wavs.is_cuda and wavs.dtype == torch.float32 and wavs.is_contiguous()) \
+                else wavs.to(self.device, torch.float32).contiguous()
+            offsets = offsets.tolist() if hasattr(offsets, 'tolist') else offsets     # (Python ints: numpy scalars are 10x slower)
+            lens = [offsets[i + 1] - offsets[i] for i in range(len(offsets) - 1)]
         offs = [0]
         for n in lens:
             offs.append(offs[-1] + n)
