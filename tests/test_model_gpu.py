@@ -220,9 +220,16 @@ def test_forward_pass_is_bitwise_reproducible(bsz, t_in):
     assert torch.equal(acts0, acts1)
 
 
-def test_deferred_readback_gives_the_same_steps():
+@pytest.mark.parametrize('frozen_conv', [False, True])
+def test_deferred_readback_gives_the_same_steps(frozen_conv):
     """``Trainer.update(defer=True)`` (the host reads step i's loss after enqueuing step i + 1) against the synchronous
-    form: same losses, gradient norm and parameters; ``run()`` reports every step exactly once."""
+    form: same losses, gradient norm and parameters; ``run()`` reports every step exactly once.
+
+    ``frozen_conv``: the variant WITHOUT the discontinuity that forces the loose bounds below.  The only non-smooth
+    function of the model is the conv block's hard clip, and its gradient mask only reaches the conv filters: with the
+    conv layers frozen (fine-tuning's ``freeze_layers``, training_utils.py:52-54) a flipped mask changes nothing that is
+    applied, what is left is the last-bit noise of the float atomics, and the round-2 tolerances hold -- tight enough to
+    tell an ordering or race error between the deferred and the synchronous path from that noise."""
     from codes.engine import PendingLoss, Trainer
     from codes.model import DeepSpeech
     kw = dict(rnn_hidden_size=96, num_rnn_layers=2, num_classes=29)
@@ -237,8 +244,12 @@ def test_deferred_readback_gives_the_same_steps():
     for mode in ('sync', 'defer', 'run'):
         torch.manual_seed(3)
         model = DeepSpeech(**kw).to('cuda')
-        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True)
+        if frozen_conv:
+            for p in model.conv.parameters():
+                p.requires_grad_(False)
+        opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3, momentum=0.9, nesterov=True)
         tr = Trainer(model, opt, device='cuda', max_norm=50)
+        assert tr._fused
         if mode == 'sync':
             losses = [tr.update(b) for b in batches]
         elif mode == 'defer':
@@ -261,13 +272,16 @@ def test_deferred_readback_gives_the_same_steps():
     # orders of magnitude more.
     for losses, norm, params, it in runs[1:]:
         np.testing.assert_allclose(losses[0], runs[0][0][0], rtol=1e-6)
-        np.testing.assert_allclose(losses, runs[0][0], rtol=1e-4)
-        np.testing.assert_allclose(norm, runs[0][1], rtol=1e-3)
+        np.testing.assert_allclose(losses, runs[0][0], rtol=1e-5 if frozen_conv else 1e-4)
+        np.testing.assert_allclose(norm, runs[0][1], rtol=1e-5 if frozen_conv else 1e-3)
         assert it == len(batches)
         for a, b in zip(params, runs[0][2]):
             d = (a - b).abs()
-            assert float(d.max()) <= 1e-4
-            assert float((d > 2e-6).float().mean()) <= 0.01
+            if frozen_conv:
+                assert float(d.max()) <= 2e-6
+            else:
+                assert float(d.max()) <= 1e-4
+                assert float((d > 2e-6).float().mean()) <= 0.01
 
 
 def test_beam_decoder_agrees_with_greedy_on_confident_outputs():
