@@ -37,6 +37,9 @@ def sanitize_inputs(out_seq_length, input_percentages):
     return (input_percentages.to('cpu', torch.float32) * out_seq_length).int()
 
 
+_STATS_DIRECT = os.environ.get('DS2_STATS_DIRECT', '1') != '0'
+
+
 class PendingLoss(object):
     """The host half of a training step whose device work is already enqueued (``Trainer.update(defer=True)``)."""
 
@@ -46,8 +49,11 @@ class PendingLoss(object):
 
     def result(self):
         if self._value is None:
-            ops.spin_wait(self.done)
-            loss_sum, sumsq, timed_out, n_inf = self.host.tolist()
+            if self.done is None:                 # the kernel wrote the slot itself: poll the memory
+                loss_sum, sumsq, timed_out, n_inf = ops.wait_step_stats(self.host)
+            else:
+                ops.spin_wait(self.done)
+                loss_sum, sumsq, timed_out, n_inf = self.host.tolist()
             if timed_out != 0:
                 ops.raise_async_error()
             self.trainer.last_grad_norm = float(sumsq) ** 0.5 * self.scale
@@ -201,13 +207,20 @@ class Trainer(object):
         model._tick('gradient norm + clip + Nesterov SGD')
         # one launch gathers what the host needs (loss sum, grad norm^2, sticky kernel-timeout flags, inf count),
         # one device->host copy brings it over
-        self._stats = ops.step_stats(costs, self._sumsq, self._stats)
         if self._host_stats is None:
             self._host_stats = [torch.empty(4, dtype=torch.float64).pin_memory() for _ in range(2)]
         slot = self._host_stats[self.iteration & 1]                       # two page-locked slots: a deferred readback
-        slot.copy_(self._stats.reshape(-1), non_blocking=True)            # survives the next step's
-        done = torch.cuda.Event()
-        done.record()
+        if _STATS_DIRECT:                                                 # survives the next step's
+            # the kernel writes the slot in host memory itself and the host polls it: no copy, no event (DS2_STATS_DIRECT=0
+            # restores them)
+            ops.arm_step_stats(slot)
+            ops.step_stats(costs, self._sumsq, slot)
+            done = None
+        else:
+            self._stats = ops.step_stats(costs, self._sumsq, self._stats)
+            slot.copy_(self._stats.reshape(-1), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
         self.iteration += 1
         pend = PendingLoss(self, slot, done, bsz, scale)
         prev, self._pending = self._pending, pend
