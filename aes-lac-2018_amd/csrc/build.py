@@ -55,16 +55,16 @@ def build_host_sanitized(out=None):
     return out
 
 
-def build_gemm_variant(name, flags):
-    """libds2hip_<name>.so with gemm.hip recompiled with ``flags`` (tools/gemm_ablate.py)."""
-    src = os.path.join(HERE, 'gemm.hip')
-    obj = os.path.join(OBJ, 'gemm_%s.o' % name)
+def build_gemm_variant(name, flags, src_name='gemm.hip'):
+    """libds2hip_<name>.so with gemm.hip (or ``src_name``) recompiled with ``flags`` (tools/gemm_ablate.py)."""
+    src = os.path.join(HERE, src_name)
+    obj = os.path.join(OBJ, '%s_%s.o' % (src_name[:-4], name))
     out = os.path.join(PKG, 'ds2hip', 'libds2hip_%s.so' % name)
     r = subprocess.run([HIPCC] + FLAGS + list(flags) + ['-c', src, '-o', obj], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed:\n%s\n%s' % (r.stdout, r.stderr))
     objs = [os.path.join(OBJ, f[:-4] + '.o') for f in sorted(os.listdir(HERE)) if f.endswith('.hip')]
-    objs = [obj if o.endswith(os.sep + 'gemm.o') else o for o in objs]
+    objs = [obj if o.endswith(os.sep + src_name[:-4] + '.o') else o for o in objs]
     r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))

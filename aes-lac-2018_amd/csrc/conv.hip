@@ -14,7 +14,7 @@
 // neighbouring frequency rows so their input windows overlap in L1/L2.
 #include <stdlib.h>
 
-#include "ds2_common.h"
+#include "split_bf16.h"
 
 namespace {
 
@@ -583,6 +583,159 @@ __global__ __launch_bounds__(256) void conv_wgrad_lds_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------- weight gradients on the bf16 matrix pipe
+// The LDS form above is bound by the f32-input MFMA (32 v_mfma_f32_32x32x2 = 2048 pipe cycles per wave and 64-step chunk;
+// 105-113 TFLOP/s).  Same workgroup geometry, staging and chunk walk here, but the products run as error-free split operands
+// (split_bf16.h) on v_mfma_f32_32x32x16_bf16: a chunk is four 16-step instructions' worth x 6 products = 768 pipe cycles.
+//   A = d(out), [32 channels][64 steps], shared by the four waves: split ONCE per chunk by the staging threads and kept in LDS
+//       as bf16 planes, [channel][16-step slab][plane][16 steps], row pitch 400 B (the fragment reads, 16 bytes per lane, of
+//       16 consecutive channels fall on 16 different 16-byte slots);
+//   B = the input window, fp32 in LDS as before: lane = tap reads its 8 consecutive (stride ST) time steps at its own shift --
+//       any alignment, so as eight ds_read_b32 -- and splits them in registers (44 vector instructions per 6 MFMAs: the
+//       vector and the matrix pipe are about evenly loaded).
+// d(bias) = the row sums of d(out): summed by the staging threads of the first tap group in fp32.
+constexpr int WS_APITCH = 400;                      // bytes per channel row: 4 slabs x 3 planes x 32 B + 16
+template <int CIN, int KF, int SF, int ST, int PADT>
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const float* __restrict__ in, const float* __restrict__ dout,
+                                                               int B, int FIN, int TIN, int FOUT, int TOUT, int nsplit,
+                                                               float* __restrict__ dw, float* __restrict__ dbias) {
+    constexpr int KT = 11, NTOT = CIN * KF * KT;
+    constexpr int WCOLS = ST * (WG_TC - 1) + KT;
+    constexpr int WG_PB = WCOLS | 1;
+    constexpr int NB = WG_NROW * WCOLS, NBI = (NB + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char sA[2][32 * WS_APITCH];
+    __shared__ float sB[2][WG_NROW * WG_PB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * 128, r0 = n0 / KT;
+    const int n = n0 + wave * 32 + lr;
+    const bool n_ok = n < NTOT;
+    const int nn = n_ok ? n : n0;
+    const int boff = (nn / KT - r0) * WG_PB + nn % KT + ST * 8 * lh;   // this lane's tap in the staged rows (+ its k half)
+    const int aoff = lr * WS_APITCH + lh * 16;
+    const int tchunks = (TOUT + WG_TC - 1) / WG_TC;
+    const int rows = B * FOUT;
+    const int myrows = (rows - (int)blockIdx.y + nsplit - 1) / nsplit;
+    const int nchunks = myrows * tchunks;
+    const int a_co = tid >> 3, a_t = (tid & 7) * 8;
+    const int a_dst = a_co * WS_APITCH + (a_t >> 4) * 96 + ((a_t >> 3) & 1) * 16;
+    int b_src[NBI], b_dst[NBI], b_x[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int idx = tid + 256 * i;
+        const int j = idx / WCOLS, x = idx - j * WCOLS;
+        const int r = r0 + j, ci = r / KF, kf = r - ci * KF;
+        b_src[i] = (idx < NB && r < CIN * KF) ? (ci * FIN + kf) * TIN + x : -1;
+        b_dst[i] = idx < NB ? j * WG_PB + x : -1;
+        b_x[i] = x;
+    }
+    float ra[8], rb[NBI];
+    int g_row = blockIdx.y, g_tc = 0;
+    auto gload = [&]() {
+        const int row = g_row, t0 = g_tc * WG_TC;
+        if (++g_tc == tchunks) {
+            g_tc = 0;
+            g_row += nsplit;
+        }
+        const int b = row / FOUT, d = row % FOUT;
+        const float* ap = dout + (((size_t)b * 32 + a_co) * FOUT + d) * TOUT + t0 + a_t;
+        if (t0 + a_t + 7 < TOUT) {
+            const f32x4u x0 = *reinterpret_cast<const f32x4u*>(ap), x1 = *reinterpret_cast<const f32x4u*>(ap + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ra[e] = x0[e];
+                ra[4 + e] = x1[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ra[e] = (t0 + a_t + e < TOUT) ? ap[e] : 0.f;
+        }
+        const int c0 = ST * t0 - PADT;
+        const float* bp = in + ((size_t)b * CIN * FIN + (size_t)SF * d) * TIN + c0;
+#pragma unroll
+        for (int i = 0; i < NBI; ++i)
+            rb[i] = (b_src[i] >= 0 && c0 + b_x[i] >= 0 && c0 + b_x[i] < TIN) ? bp[b_src[i]] : 0.f;
+    };
+    const bool sum_bias = blockIdx.x == 0;               // d(bias): the staging threads of the first tap group
+    float bsum = 0.f;
+    auto lstore = [&](int buf) {
+        unsigned int pl[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split3(ra[2 * c], ra[2 * c + 1], pl[0][c], pl[1][c], pl[2][c]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            *reinterpret_cast<uint4*>(sA[buf] + a_dst + q * 32) = make_uint4(pl[q][0], pl[q][1], pl[q][2], pl[q][3]);
+        if (sum_bias) bsum += ((ra[0] + ra[1]) + (ra[2] + ra[3])) + ((ra[4] + ra[5]) + (ra[6] + ra[7]));
+#pragma unroll
+        for (int i = 0; i < NBI; ++i)
+            if (b_dst[i] >= 0) sB[buf][b_dst[i]] = rb[i];
+    };
+    f32x16 acc, acc_lo;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc_lo[r] = 0.f;
+    if (nchunks > 0) {
+        gload();
+        lstore(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+#ifndef DS2_WGRAD_ABL
+#define DS2_WGRAD_ABL 0        // timing-only ablations (results WRONG): 1 no MFMAs, 2 no operand split, 4 no global loads in the
+#endif                         // loop, 8 no atomics, 16 no LDS stores in the loop
+        if (c + 1 < nchunks && !(DS2_WGRAD_ABL & 4)) gload();                    // in flight under this chunk's MFMAs
+        const char* pa = sA[buf] + aoff;
+        const float* pb = sB[buf] + boff;
+#pragma unroll
+        for (int ks = 0; ks < WG_TC / 16; ++ks) {
+            bf16x8 a[3], b[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const bf16x8*>(pa + ks * 96 + q * 32);
+            float bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = pb[ST * (16 * ks + e)];
+            unsigned int p[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (DS2_WGRAD_ABL & 2) {
+                    p[0][e] = __builtin_bit_cast(unsigned int, bv[2 * e]);
+                    p[1][e] = __builtin_bit_cast(unsigned int, bv[2 * e + 1]);
+                    p[2][e] = p[0][e] ^ p[1][e];
+                } else
+                    split3(bv[2 * e], bv[2 * e + 1], p[0][e], p[1][e], p[2][e]);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[q] = __builtin_bit_cast(bf16x8, make_uint4(p[q][0], p[q][1], p[q][2], p[q][3]));
+            if (DS2_WGRAD_ABL & 1) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r + 4 * q] += __builtin_bit_cast(f32x4, a[q])[r] + __builtin_bit_cast(f32x4, b[q])[r];
+            } else
+                split_mfma2<6>(a, b, acc, acc_lo);
+        }
+        if (c + 1 < nchunks && !(DS2_WGRAD_ABL & 16)) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (n_ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (DS2_WGRAD_ABL & 8) {
+                if (acc[r] + acc_lo[r] == 12345.678f) dw[(size_t)co * NTOT + n] = acc[r];
+            } else
+            atomicAdd(&dw[(size_t)co * NTOT + n], acc[r] + acc_lo[r]);
+        }
+    }
+    if (sum_bias) {                                      // eight staging threads (adjacent lanes) per channel
+        bsum += __shfl_xor(bsum, 1, 64);
+        bsum += __shfl_xor(bsum, 2, 64);
+        bsum += __shfl_xor(bsum, 4, 64);
+        if ((tid & 7) == 0) atomicAdd(&dbias[a_co], bsum);
+    }
+}
+
 struct ConvGeom {
     int cin, kf, kt, sf, st, padt, fin, fout;
 };
@@ -742,7 +895,21 @@ extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, in
     if (nsplit < 1) nsplit = 1;
     dim3 grid(ntn, nsplit), block(256);
     const bool lds_form = !(getenv("DS2_CONV_WGRAD_LDS") && getenv("DS2_CONV_WGRAD_LDS")[0] == '0');
-    if (which == 1 && lds_form) {
+    // DS2_CONV_WGRAD_BF16 = 0: the LDS form on the f32-input MFMA (A/B timing, tests); default: split operands on the bf16 pipe
+    const bool split_form = lds_form && !(getenv("DS2_CONV_WGRAD_BF16") && getenv("DS2_CONV_WGRAD_BF16")[0] == '0');
+    if (split_form) {
+        int split = which == 1 ? 256 : 105;              // the LDS form's workgroup counts (below)
+        const char* e = getenv(which == 1 ? "DS2_CONV1_WGRAD_SPLIT" : "DS2_CONV_WGRAD_SPLIT");
+        if (e) split = atoi(e);
+        if (split > rows) split = rows;
+        if (split < 1) split = 1;
+        if (which == 1)
+            hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 41, 2, 2, 10>), dim3(ds2_cdiv(ntot, 128), split), block, 0, st, in,
+                               d_out, B, g.fin, tin, g.fout, tout, split, d_weight, d_bias);
+        else
+            hipLaunchKernelGGL((conv_wgrad_split_kernel<32, 21, 2, 1, 0>), dim3(ds2_cdiv(ntot, 128), split), block, 0, st, in,
+                               d_out, B, g.fin, tin, g.fout, tout, split, d_weight, d_bias);
+    } else if (which == 1 && lds_form) {
         // conv1 through LDS (round 4): 4 groups of 128 taps x up to 256 row splits ~ 1000 workgroups, ~4 per CU
         int split = 256;
         if (getenv("DS2_CONV1_WGRAD_SPLIT")) split = atoi(getenv("DS2_CONV1_WGRAD_SPLIT"));

@@ -303,14 +303,49 @@ def test_conv2_wgrad_lds_form_repeatable_at_training_size(ops, monkeypatch):
     dw_ref, db_ref = torch.empty(32, 32, 21, 11, device=DEV), torch.empty(32, device=DEV)
     ops.conv_wgrad(2, a1, dy2, t1, dw_ref, db_ref)
     monkeypatch.setenv('DS2_CONV_WGRAD_LDS', '1')
-    worst_w = worst_b = 0.0
-    for _ in range(50):
-        dw, db = torch.empty_like(dw_ref), torch.empty_like(db_ref)
-        ops.conv_wgrad(2, a1, dy2, t1, dw, db)
-        worst_w = max(worst_w, float((dw - dw_ref).abs().max()))
-        worst_b = max(worst_b, float((db - db_ref).abs().max()))
-    assert worst_w <= 5e-6 * float(dw_ref.abs().max())
-    assert worst_b <= 5e-6 * float(db_ref.abs().max())
+    for bf16 in ('0', '1'):                              # the f32-input MFMA form, then the split-operand form (the default)
+        monkeypatch.setenv('DS2_CONV_WGRAD_BF16', bf16)
+        worst_w = worst_b = 0.0
+        for _ in range(50):
+            dw, db = torch.empty_like(dw_ref), torch.empty_like(db_ref)
+            ops.conv_wgrad(2, a1, dy2, t1, dw, db)
+            worst_w = max(worst_w, float((dw - dw_ref).abs().max()))
+            worst_b = max(worst_b, float((db - db_ref).abs().max()))
+        assert worst_w <= 5e-6 * float(dw_ref.abs().max()), bf16
+        assert worst_b <= 5e-6 * float(db_ref.abs().max()), bf16
+
+
+@pytest.mark.parametrize('which,bsz,t_in', [(2, 3, 139), (2, 10, 75), (1, 2, 301), (1, 5, 130)])
+def test_conv_wgrad_families_agree(ops, monkeypatch, which, bsz, t_in):
+    """The weight gradients three ways against an fp64 reference: the direct kernel, the operands-through-LDS kernel on the
+    f32-input matrix instruction, and (round 4, the default) the same with error-free split operands on the bf16 matrix pipe
+    (csrc/conv.hip conv_wgrad_split_kernel).  Error relative to sum |d(out)| |in| per filter entry, as in the GEMM and
+    conv2-forward family tests: the split form no worse than the f32 forms.  Operands in the training ranges: conv1's input
+    is a normalised spectrogram, conv2's the clipped-ReLU output of conv1; d(out) small and same-signed in places."""
+    torch.manual_seed(100 * which + bsz)
+    cin, fin, kf = (1, 161, 41) if which == 1 else (32, 61, 21)
+    x = (torch.randn(bsz, cin, fin, t_in) if which == 1 else torch.rand(bsz, cin, fin, t_in) * 20.0)
+    w = (torch.randn(32, cin, kf, 11) / np.sqrt(cin * kf * 11)).double().requires_grad_(True)
+    b = torch.zeros(32, dtype=torch.float64, requires_grad=True)
+    out = _conv_ref(which, x.double(), w, b)
+    dy = torch.randn(tuple(out.shape)) * 1e-3 + 2e-4
+    out.backward(dy.double())
+    wa = torch.ones_like(w).requires_grad_(True)                       # sum |dy| |x| per filter entry: the error's scale
+    _conv_ref(which, x.double().abs(), wa, torch.zeros(32, dtype=torch.float64)).backward(dy.double().abs())
+    scale = wa.grad
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    err, errb = {}, {}
+    for name, env in (('direct', {'DS2_CONV_WGRAD_LDS': '0'}), ('lds-f32', {'DS2_CONV_WGRAD_LDS': '1', 'DS2_CONV_WGRAD_BF16': '0'}),
+                      ('split', {'DS2_CONV_WGRAD_LDS': '1', 'DS2_CONV_WGRAD_BF16': '1'})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dw, db = torch.empty(32, cin, kf, 11, device=DEV), torch.empty(32, device=DEV)
+        ops.conv_wgrad(which, xd, dyd, t_in, dw, db)
+        err[name] = float(((dw.cpu().double() - w.grad).abs() / scale).max())
+        errb[name] = float((db.cpu().double() - b.grad).abs().max() / float(dy.abs().sum(dim=(0, 2, 3)).max()))
+    assert err['direct'] <= 2e-6 and err['lds-f32'] <= 2e-6, err
+    assert err['split'] <= 1.25 * max(err['direct'], err['lds-f32']) + 1e-8, err
+    assert max(errb.values()) <= 2e-6, errb
 
 
 @pytest.mark.parametrize('bsz,t1', [(2, 56), (1, 33), (3, 129), (10, 150), (6, 400), (2, 1501 // 2)])

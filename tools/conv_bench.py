@@ -2,6 +2,8 @@
 import os, sys
 sys.path.insert(0, 'aes-lac-2018_amd'); sys.path.insert(0, '.')
 import torch, numpy as np
+from ds2hip import lib
+if os.environ.get("DS2_LIB_VARIANT"): lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), "libds2hip_%s.so" % os.environ["DS2_LIB_VARIANT"])
 from ds2hip import ops
 B, t_in = int(os.environ.get('BSZ', '10')), int(os.environ.get('TIN', '830'))
 t1, t = ops.conv_out_frames(t_in)
