@@ -122,6 +122,12 @@ class _DS2Function(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+# Compute units a backward recurrence launch leaves to the side stream's weight-gradient GEMMs (ds2_gru_bidir_bwd_persistent_ex):
+# same-box A/B of the whole B = 10 step, ms with a synchronisation per step, 48 steps: 52 CUs free (24 units per workgroup)
+# 15.66, 82 free (28 units) 15.57 -- the slower recurrence form wins because dW_ih of the layer above then hides beside it too.
+_BWD_SPARE_CUS = int(os.environ.get('DS2_GRU_BWD_SPARE', '82'))
+
+
 class DeepSpeech(nn.Module):
     __version__ = '0.0.1'
 
@@ -460,7 +466,10 @@ class DeepSpeech(nn.Module):
             if pending is not None:
                 gate = torch.cuda.Event()
                 gate.record(main)
-            ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid)           # gates -> d(gi), ghn -> d(gh_n)
+            # CUs to leave free beside the launch: none for the top layer (nothing is queued beside it yet -- the widest, fastest
+            # grid), room for the side stream's weight-gradient GEMMs of the layer above under the others
+            spare = 0 if (li == nl - 1 or side is None) else _BWD_SPARE_CUS
+            ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid, spare_cus=spare)   # gates -> d(gi), ghn -> d(gh_n)
             self._tick('BiGRU recurrence backward (weight-gradient GEMMs beside it)')
             if pending is not None:
                 pending(gate)

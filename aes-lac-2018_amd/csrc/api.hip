@@ -15,4 +15,4 @@ void ds2_set_error(const char* fmt, ...) {
 extern "C" const char* ds2_last_error(void) { return g_err; }
 // = DS2_ABI_VERSION of include/ds2hip.h (the header is C documentation of the ABI and is not included by the sources; the
 // CPU test suite compares the two numbers)
-extern "C" int ds2_version(void) { return 400; }
+extern "C" int ds2_version(void) { return 401; }

@@ -2634,8 +2634,24 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
     return DS2_OK;
 }
 
+// spare_cus: how many compute units the caller wants LEFT FREE beside this launch (work it has queued on other streams: the
+// weight-gradient GEMMs of the layer above, a collective); < 0 = the library's default.  Where the 4x4x1 forms run three batch
+// parts with the speculative hand-off (B = 9 .. 12) a workgroup may own 20, 24 or 28 units, i.e. 240, 204 or 174 workgroups at
+// H = 800 -- measured at B = 10, us per step stand-alone: 2.65 / 2.82 / 3.0 -- and inside a training step the SLOWER forms win
+// wherever the side stream has GEMMs waiting (they only get the CUs a recurrence launch leaves free): the launch picks the
+// widest grid that leaves spare_cus free.  Everywhere else the hint changes nothing.
+extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float* hout, const float* d_out,
+                                               const float* w_hh_t, void* sync_ws, int T, int B, int H, int spare_cus,
+                                               void* stream);
+
 extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* hout, const float* d_out,
                                             const float* w_hh_t, void* sync_ws, int T, int B, int H, void* stream) {
+    return ds2_gru_bidir_bwd_persistent_ex(G, ghn, hout, d_out, w_hh_t, sync_ws, T, B, H, -1, stream);
+}
+
+extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float* hout, const float* d_out,
+                                               const float* w_hh_t, void* sync_ws, int T, int B, int H, int spare_cus,
+                                               void* stream) {
     DS2_CHECK_ARG(G && ghn && hout && d_out && w_hh_t && sync_ws);
     DS2_CHECK_ARG(T > 0 && B > 0 && H > 0);
     if (!persistent_ok(B, H)) {
@@ -2686,8 +2702,20 @@ extern "C" int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* h
                                       : launch_bwd_persistent_p2b<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
                  : ((B + 1) / 2 <= 16 ? launch_bwd_persistent_p2<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
                                       : launch_bwd_persistent_p2<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st));
-    else if (use4 && ngi_ok && parts == 3 && proto != 0 && getenv("DS2_GRU_BWD_WIDE") && getenv("DS2_GRU_BWD_WIDE")[0] == '1')
-        ok = launch_bwd_persistent4<7, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);   // 28 units: 174 CUs
+    else if (use4 && ngi_ok && parts == 3 && proto != 0) {
+        // units per workgroup by the CUs to leave free (see above); DS2_GRU_BWD_WIDE = 0 / 1 / 2 forces 24 / 28 / 20 (A/B timing)
+        const int cus = device_cus();
+        int want = spare_cus < 0 ? 52 : spare_cus;
+        const char* w = getenv("DS2_GRU_BWD_WIDE");
+        if (w && w[0] >= '0' && w[0] <= '2') want = w[0] == '0' ? 52 : (w[0] == '1' ? 82 : 0);
+        const int g20 = 6 * ds2_cdiv(H, 20), g24 = 6 * ds2_cdiv(H, 24), g28 = 6 * ds2_cdiv(H, 28);
+        if (g20 <= max_persistent_wgs() && g20 > g24 && cus - g20 >= want)
+            ok = launch_bwd_persistent4<5, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);   // 240 workgroups
+        else if (cus - g24 >= want || g28 >= g24)
+            ok = launch_bwd_persistent4<6, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);   // 204
+        else
+            ok = launch_bwd_persistent4<7, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);   // 174
+    }
     else if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);

@@ -50,6 +50,7 @@ SIGNATURES = {
     'ds2_gru_persistent_supported': (_I, [_I, _I]),
     'ds2_gru_bidir_fwd_persistent': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ds2_gru_bidir_bwd_persistent': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'ds2_gru_bidir_bwd_persistent_ex': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'ds2_softmax_rows': (_I, [_P, _I, _I, _P, _P]),
     'ds2_argmax_rows': (_I, [_P, _I, _I, _P, _P]),
     'ds2_greedy_collapse': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
@@ -66,7 +67,7 @@ SIGNATURES = {
     'ds2_ctc_beam_search': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
 }
 
-ABI_VERSION = 400            # DS2_ABI_VERSION of include/ds2hip.h: the revision this table (and ops.py) is written against
+ABI_VERSION = 401            # DS2_ABI_VERSION of include/ds2hip.h: the revision this table (and ops.py) is written against
 
 _lib = None
 

@@ -439,11 +439,13 @@ def gru_bidir_fwd(gates, w_hh, t, bsz, hid):
     return ghn, hout
 
 
-def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid):
+def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=-1):
+    """``spare_cus``: compute units to leave free beside the launch for work queued on other streams (-1: the library's
+    default; see ds2_gru_bidir_bwd_persistent_ex in include/ds2hip.h)."""
     if _use_persistent(gates.device, bsz, hid):
         try:
-            lib.call('ds2_gru_bidir_bwd_persistent', gates, ghn, hout, d_out, w_hh_t,
-                     _gru_sync_ws(gates.device, bsz, hid), t, bsz, hid)
+            lib.call('ds2_gru_bidir_bwd_persistent_ex', gates, ghn, hout, d_out, w_hh_t,
+                     _gru_sync_ws(gates.device, bsz, hid), t, bsz, hid, int(spare_cus))
             return
         except lib.Ds2Error as e:
             if e.code != lib.ERR_UNSUPPORTED or GRU_MODE == 'persistent':

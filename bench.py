@@ -267,25 +267,32 @@ def gru_pass_roofline(model, bsz, t):
     w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
     gates = 0.1 * torch.randn(t, bsz, 2, 3 * hid, device=dev)
     d_out = 0.01 * torch.randn(t, bsz, hid, device=dev)
-    res = {'fwd': [], 'bwd': []}
-    for _ in range(5):
+    # The backward launch exists in forms that leave different numbers of CUs to the side stream's weight-gradient GEMMs
+    # (codes/model.py: none under the top layer, _BWD_SPARE_CUS under the others): both are timed, and 'bwd' is what a step
+    # launches -- one launch of the first, num_layers - 1 of the second.
+    from codes.model import _BWD_SPARE_CUS
+    res = {'fwd': [], 'bwd_top': [], 'bwd_below': []}
+    for rep in range(10):
         g = gates.clone()
         torch.cuda.synchronize()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
         ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
         e[1].record()
-        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
+        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=0 if rep % 2 == 0 else _BWD_SPARE_CUS)
         e[2].record()
         torch.cuda.synchronize()
         ops.check_async_errors()
         res['fwd'].append(e[0].elapsed_time(e[1]) * 1e-3)
-        res['bwd'].append(e[1].elapsed_time(e[2]) * 1e-3)
+        res['bwd_top' if rep % 2 == 0 else 'bwd_below'].append(e[1].elapsed_time(e[2]) * 1e-3)
     flop = 2.0 * 2 * bsz * hid * 3 * hid * t                           # both directions, all T steps
     out = {}
-    for name in ('fwd', 'bwd'):
+    for name in ('fwd', 'bwd_top', 'bwd_below'):
         dur = float(np.median(res[name]))
         out[name] = (flop / dur / 1e12, dur, flop)
+    nl = model._num_rnn_layers
+    dur = (out['bwd_top'][1] + (nl - 1) * out['bwd_below'][1]) / nl     # the mean launch of a step
+    out['bwd'] = (flop / dur / 1e12, dur, flop)
     return out
 
 
@@ -811,6 +818,11 @@ def main():
                                  'per CU) resp. 200 (fwd, 20 units, k dealt evenly) v_mfma_f32_4x4x1 per SIMD at 8.8 cycles / '
                                  '2.4 GHz; the gate / reduction skeleton (0.4 us on the chain today) has no hardware floor'},
                      'flop_per_launch': flop,
+                     'launch_forms_us': {
+                         'top layer (nothing queued beside it: the widest grid)': round(roof['bwd_top'][1] * 1e6, 1),
+                         'layers below (CUs left to the weight-gradient GEMMs of the layer above)': round(roof['bwd_below'][1] * 1e6, 1),
+                         'note': 'avg_launch_us = the mean launch of a step (1 : num_layers - 1), each form timed stand-alone; '
+                                 'ds2_gru_bidir_bwd_persistent_ex, include/ds2hip.h'},
                      'fwd_kernel_tflops': round(roof['fwd'][0], 3),
                      'fwd_us_per_time_step': round(roof['fwd'][1] * 1e6 / t_mean, 3),
                      'whole_step_tflops_per_gpu': round(step_tflops, 3),

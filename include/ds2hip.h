@@ -39,7 +39,7 @@ const char* ds2_last_error(void);
  * have changed between revisions without a change of symbol name (round 3: an amplitude-scale argument in
  * ds2_pcm16_to_float / ds2_gain_requantize; round 4: ds2_conv2_dgrad takes the size of its workspace), so a binding built
  * against another revision mis-passes arguments.  ds2hip/lib.py refuses to load a library whose number differs. */
-#define DS2_ABI_VERSION 400
+#define DS2_ABI_VERSION 401
 int ds2_version(void);
 
 /* ------------------------------------------------------------------ frontend
@@ -229,6 +229,13 @@ int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, const float*
                                  int B, int H, void* stream);
 int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* hout, const float* d_out,
                                  const float* w_hh_t, void* sync_ws, int T, int B, int H, void* stream);
+/* The same with a hint (ABI revision 401): spare_cus = compute units the caller wants left FREE beside this launch for work
+ * it has queued on other streams (the weight-gradient GEMMs of the layer above, a collective); < 0 = the library's default.
+ * For B = 9 .. 12 the kernel exists with 20, 24 or 28 hidden units per workgroup (240 / 204 / 174 workgroups at H = 800;
+ * 2.65 / 2.82 / 3.0 us per time step stand-alone at B = 10): the launch takes the widest grid that leaves spare_cus free.
+ * Same results, same workspace; elsewhere the hint is ignored. */
+int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float* hout, const float* d_out,
+                                    const float* w_hh_t, void* sync_ws, int T, int B, int H, int spare_cus, void* stream);
 
 /* ------------------------------------------------------------------ output head helpers
  * softmax over the last dim of (rows, A) (eval branch, codes/model.py:204-205) and the argmax

@@ -520,7 +520,7 @@ def test_gru_persistent_mfma_forms_agree_with_step_kernels(ops, monkeypatch, fwd
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=3e-5, rtol=1e-4)
 
 
-def _long_sequence_case(ops, monkeypatch, bsz, reps, during=None):
+def _long_sequence_case(ops, monkeypatch, bsz, reps, during=None, spare_cus=(-1,)):
     t, hid = 746, 800
     torch.manual_seed(1)
     k = 1.0 / hid ** 0.5
@@ -529,7 +529,7 @@ def _long_sequence_case(ops, monkeypatch, bsz, reps, during=None):
     gi = torch.randn(t, bsz, 2, 3 * hid).to(DEV)
     d_out = (0.1 * torch.randn(t, bsz, hid)).to(DEV)
     res = {}
-    for mode in ['step'] + ['persistent'] * reps:
+    for rep, mode in enumerate(['step'] + ['persistent'] * reps):
         monkeypatch.setattr(ops, 'GRU_MODE', mode)
         g = gi.clone()
         torch.cuda.synchronize()
@@ -537,7 +537,7 @@ def _long_sequence_case(ops, monkeypatch, bsz, reps, during=None):
             during()
         ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
         fwd = (g.clone(), ghn.clone(), hout.clone())
-        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
+        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=spare_cus[rep % len(spare_cus)])
         torch.cuda.synchronize()
         ops.check_async_errors()
         cur = fwd + (g, ghn)
@@ -558,6 +558,15 @@ def test_gru_persistent_long_sequence_matches_step_kernels(ops, monkeypatch, bsz
     size of the speculative protocol), 13 and 16 (forward: the first of the two-part split-operand forms; backward: the 4x4x1
     forms with the counted protocol), 17 (the first of the two-part 16x16x4 backward forms), 32 and 64."""
     _long_sequence_case(ops, monkeypatch, bsz, 3 if bsz <= 12 else 2)
+
+
+@pytest.mark.parametrize('bsz', [9, 10, 12])
+def test_gru_backward_forms_by_spare_cus_match_step_kernels(ops, monkeypatch, bsz):
+    """ds2_gru_bidir_bwd_persistent_ex: the three-part speculative backward kernel with 20, 24 and 28 hidden units per workgroup
+    (240 / 204 / 174 workgroups at H = 800: spare_cus 0, 52, 82 -- what codes/model.py asks for under the top layer and under
+    the others) against the launch-per-step kernels at T = 746; twice each, interleaved, on ONE exchange workspace (the ring
+    layout does not depend on the form: a launch must not read what another form's launch left there)."""
+    _long_sequence_case(ops, monkeypatch, bsz, 6, spare_cus=(0, 82, 52))
 
 
 @pytest.mark.parametrize('bsz,fwd_bf16,bwd_bf16', [(17, '0', '0'), (32, '0', '0'), (64, '0', '0'), (17, '1', '1'), (32, '1', '1'),
