@@ -2639,7 +2639,9 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
 // parts with the speculative hand-off (B = 9 .. 12) a workgroup may own 20, 24 or 28 units, i.e. 240, 204 or 174 workgroups at
 // H = 800 -- measured at B = 10, us per step stand-alone: 2.65 / 2.82 / 3.0 -- and inside a training step the SLOWER forms win
 // wherever the side stream has GEMMs waiting (they only get the CUs a recurrence launch leaves free): the launch picks the
-// widest grid that leaves spare_cus free.  Everywhere else the hint changes nothing.
+// widest grid that leaves spare_cus free.  Everywhere else the hint changes nothing -- measured for the two-part forms (B = 5 .. 8:
+// 16 / 20 / 24 units per workgroup = 200 / 160 / 136 workgroups, 2.34 / 2.56 / 2.79 us per step at B = 8): there the narrower
+// grids LOSE in the whole step (B = 8 x 15 s: 23.2 / 23.6 / 24.1 ms), the recurrence pays more than the hidden GEMMs return.
 extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float* hout, const float* d_out,
                                                const float* w_hh_t, void* sync_ws, int T, int B, int H, int spare_cus,
                                                void* stream);
