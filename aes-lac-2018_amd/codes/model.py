@@ -438,6 +438,25 @@ class DeepSpeech(nn.Module):
         # that started behind a 0.38 ms dW_hh GEMM).
         acc_beta = 1.0 if prezeroed else 0.0
         pending = None
+        # The dX GEMMs split K and add their partial products with atomics, so their outputs must start from zero.  ONE buffer
+        # for the five layers, cleared by ONE fill on its own normal-priority stream here, at the start of the backward pass
+        # (done long before the first dX GEMM, a recurrence launch away), with ONE pair of events -- a fill and two events per
+        # layer put two marker packets in front of every recurrence launch and a cross-stream wait in front of every dX GEMM
+        # (~30 us of idle chain per layer in the kernel trace; the chain must not wait for the low-priority weight-gradient
+        # stream's backlog either: hence the stream of its own).
+        dx_all, dx_ready, dx_off = None, None, 0
+        if side is not None:
+            fill = self._fill_stream(gflat.device)
+            total = rows * (hid * (nl - 1) + self._rnn_input_size)
+            dx_all = torch.empty((total,), dtype=torch.float32, device=gflat.device)
+            dx_all.record_stream(fill)
+            alloc_ev = torch.cuda.Event()
+            alloc_ev.record(main)
+            fill.wait_event(alloc_ev)
+            with torch.cuda.stream(fill):
+                dx_all.zero_()
+                dx_ready = torch.cuda.Event()
+                dx_ready.record(fill)
         for li in range(nl - 1, -1, -1):
             rec = sv['layers'][li]
             layer = self.rnns[li]
@@ -446,23 +465,10 @@ class DeepSpeech(nn.Module):
             w_ih = self._pair(r.weight_ih_l0, r.weight_ih_l0_reverse)
             w_hh_t = sv['w_hh_t'][li]                                               # transposed during forward
             gates, ghn, hout = rec['gates'], rec['ghn'], rec['hout']
-            # The dX GEMM below splits K and adds its partial products with atomics, so its output must start from zero: the
-            # fill (16 MB) is issued on the SIDE stream in front of the recurrence launch and runs beside it, instead of on
-            # the chain behind it (where, sharing the chip with the side stream's dW_ih GEMM, it took ~30 us per layer)
-            # -- on its OWN normal-priority stream: the chain waits for this fill, and behind the low-priority weight-gradient
-            # stream's backlog (large batches, or RCCL channel kernels sharing the chip) that wait would be a priority inversion
-            dx_buf, dx_ready = None, None
-            if side is not None:
-                fill = self._fill_stream(gflat.device)
-                dx_buf = torch.empty((rows, n_in), dtype=gates.dtype, device=gates.device)
-                dx_buf.record_stream(fill)
-                alloc_ev = torch.cuda.Event()
-                alloc_ev.record(main)
-                fill.wait_event(alloc_ev)
-                with torch.cuda.stream(fill):
-                    dx_buf.zero_()
-                    dx_ready = torch.cuda.Event()
-                    dx_ready.record(fill)
+            dx_buf = None
+            if dx_all is not None:
+                dx_buf = dx_all[dx_off:dx_off + rows * n_in].view(rows, n_in)
+                dx_off += rows * n_in
             if pending is not None:
                 gate = torch.cuda.Event()
                 gate.record(main)
@@ -476,7 +482,9 @@ class DeepSpeech(nn.Module):
                 pending = None
             dgi = gates.view(rows, 6 * hid)
             if dx_buf is not None:
-                main.wait_event(dx_ready)
+                if dx_ready is not None:
+                    main.wait_event(dx_ready)                                       # once: every later layer's slice is behind it
+                    dx_ready = None
                 dxin = ops.gemm(dgi, w_ih, out=dx_buf, beta=1.0, split_k=0)         # (rows, n_in): on the chain
             else:
                 dxin = ops.gemm(dgi, w_ih, split_k=0)
