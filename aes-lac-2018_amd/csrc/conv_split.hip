@@ -364,9 +364,12 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
     // taps, a padded copy of d(out) to make).  Inside the training step it runs beside the side stream's bf16 GEMMs: always
     // on, 240-step runs of the B = 10 bin mix: 16.58 / 16.63 / 16.67 ms against 16.77 / 16.78 / 16.74 with the direct kernel.
     // DS2_CONV_SPLIT_DGRAD = 0 / 1 forces a choice (read per call: the tests switch it); default: from B * T1 >=
-    // DS2_CONV_SPLIT_DGRAD_MIN (3500) input columns.
+    // DS2_CONV_SPLIT_DGRAD_MIN input columns.  Round 4 (the weight-gradient kernels now leave the tail of the backward pass
+    // earlier): same-box A/B of the whole B = 10 step, ms, threshold 3500 (the round-3 default: bins under 7 s on the direct
+    // kernel) 15.24-15.32, never 15.26-15.28, always 15.15-15.18; thresholds 0 / 1000 / 2000 equal (15.02-15.08 on another
+    // box): 1000.
     const char* on = getenv("DS2_CONV_SPLIT_DGRAD");
-    static const int dgrad_min = getenv("DS2_CONV_SPLIT_DGRAD_MIN") ? atoi(getenv("DS2_CONV_SPLIT_DGRAD_MIN")) : 3500;
+    static const int dgrad_min = getenv("DS2_CONV_SPLIT_DGRAD_MIN") ? atoi(getenv("DS2_CONV_SPLIT_DGRAD_MIN")) : 1000;
     if (on ? on[0] != '1' : (long)B * t1 < dgrad_min) return 1;
     const int T = t1 - 10, TP = T + 20;
     const unsigned long long a_bytes = 4ull * B * 32 * 41 * TP, o_elems = 1ull * B * 32 * 61 * t1;

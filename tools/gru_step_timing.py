@@ -11,12 +11,13 @@ torch.manual_seed(0)
 w_hh = ((torch.rand(2, 3*hid, hid)*2-1)/hid**0.5).cuda()
 w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3*hid, hid), ops.transpose2d(w_hh[1], 3*hid, hid)], 0)
 gates = 0.1*torch.randn(t, bsz, 2, 3*hid, device='cuda'); d_out = 0.01*torch.randn(t, bsz, hid, device='cuda')
+spare = int(os.environ.get('SPARE_CUS', '-1'))      # CUs the backward launch leaves free (-1: the library's default, 52)
 res = {'fwd': [], 'bwd': []}
 for _ in range(6):
     g = gates.clone(); torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     e[0].record(); ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid); e[1].record()
-    ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid); e[2].record(); torch.cuda.synchronize()
+    ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=spare); e[2].record(); torch.cuda.synchronize()
     res['fwd'].append(e[0].elapsed_time(e[1])*1e3/t); res['bwd'].append(e[1].elapsed_time(e[2])*1e3/t)
 print('T=%d ' % t, end='')
-print('DBG=%s B=%d  fwd %.2f us/step  bwd %.2f us/step' % (os.environ.get('DS2_GRU_DBG','0'), bsz, np.median(res['fwd']), np.median(res['bwd'])))
+print('DBG=%s B=%d spare_cus=%d  fwd %.2f us/step  bwd %.2f us/step' % (os.environ.get('DS2_GRU_DBG','0'), bsz, spare, np.median(res['fwd']), np.median(res['bwd'])))
