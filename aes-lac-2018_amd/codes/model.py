@@ -474,7 +474,11 @@ class DeepSpeech(nn.Module):
                 gate.record(main)
             # CUs to leave free beside the launch: none for the top layer (nothing is queued beside it yet -- the widest, fastest
             # grid), room for the side stream's weight-gradient GEMMs of the layer above under the others
-            spare = 0 if (li == nl - 1 or side is None) else _BWD_SPARE_CUS
+            # (data-parallel runs: the head's all-reduce is in flight beside the top layer's launch, and RCCL's channel
+            # kernels -- up to NCCL_MAX_NCHANNELS = 32 workgroups that may be WAITING for a peer -- must not share the chip with
+            # a grid that needs 240 of its 256 CUs resident at once: room for them there too)
+            top_spare = 0 if grad_ready is None else 40
+            spare = (top_spare if li == nl - 1 else _BWD_SPARE_CUS) if side is not None else top_spare
             ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid, spare_cus=spare)   # gates -> d(gi), ghn -> d(gh_n)
             self._tick('BiGRU recurrence backward (weight-gradient GEMMs beside it)')
             if pending is not None:
