@@ -811,12 +811,14 @@ def main():
                      'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                      'avg_launch_us': round(dur * 1e6, 1), 'us_per_time_step': round(dur * 1e6 / t_mean, 3),
                      'floor_us_per_step': {
-                         'handoff_all_to_all': 1.3, 'matrix_phase_bwd': 1.06, 'matrix_phase_fwd': 0.73, 'sum_bwd': 2.36,
-                         'sum_fwd': 2.03,
+                         'handoff_all_to_all': 1.3, 'matrix_phase_bwd_top_layer_form': 0.83, 'matrix_phase_bwd_lower_layers_form': 1.17,
+                         'matrix_phase_fwd': 0.73, 'sum_bwd_top_layer_form': 2.13, 'sum_bwd_lower_layers_form': 2.47, 'sum_fwd': 2.03,
                          'note': 'measured floors at B = 10, H = 800: a two-operation (store, load) all-to-all hand-off across '
-                                 'XCDs costs 1.3-1.5 us (tools/spec_handoff_probe.hip); the matrix phase is 288 (bwd, 24 units '
-                                 'per CU) resp. 200 (fwd, 20 units, k dealt evenly) v_mfma_f32_4x4x1 per SIMD at 8.8 cycles / '
-                                 '2.4 GHz; the gate / reduction skeleton (0.4 us on the chain today) has no hardware floor'},
+                                 'XCDs costs 1.3-1.5 us (tools/spec_handoff_probe.hip); the matrix phase is 200 / 280 (bwd: 20 '
+                                 'units per CU under the top layer, 28 under the others, where the launch leaves 82 CUs to the '
+                                 'weight-gradient GEMMs) resp. 200 (fwd, 20 units, k dealt evenly) v_mfma_f32_4x4x1 per SIMD at '
+                                 '8.8-10 cycles / 2.4 GHz; the gate / reduction skeleton (0.4 us on the chain today) has no '
+                                 'hardware floor'},
                      'flop_per_launch': flop,
                      'launch_forms_us': {
                          'top layer (nothing queued beside it: the widest grid)': round(roof['bwd_top'][1] * 1e6, 1),
