@@ -284,6 +284,32 @@ def test_deferred_readback_gives_the_same_steps(frozen_conv):
                 assert float((d > 2e-6).float().mean()) <= 0.01
 
 
+def test_step_statistics_readback_paths_agree(monkeypatch):
+    """The step's one readback two ways: the statistics kernel writing the trainer's page-locked slot itself (the default;
+    the host polls the memory) and the round-3 path (device buffer, non-blocking copy, polled event; DS2_STATS_DIRECT=0).
+    Same loss and gradient norm, synchronous and deferred."""
+    from codes import engine
+    from codes.model import DeepSpeech
+    kw = dict(rnn_hidden_size=64, num_rnn_layers=2, num_classes=29)
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal((3, 150, 161)).astype(np.float32))
+    lens = [5, 3, 7]
+    labels = torch.from_numpy(rng.integers(1, 29, size=sum(lens)).astype(np.int32))
+    batch = (x, labels, torch.ones(3), torch.tensor(lens, dtype=torch.int32))
+    got = {}
+    for direct in (True, False):
+        monkeypatch.setattr(engine, '_STATS_DIRECT', direct)
+        torch.manual_seed(5)
+        model = DeepSpeech(**kw).to('cuda')
+        tr = engine.Trainer(model, torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, nesterov=True), device='cuda',
+                            max_norm=50)
+        first = tr.update(batch)
+        pend = tr.update(batch, defer=True)
+        assert (pend.done is None) == direct
+        got[direct] = (first, tr.last_grad_norm, pend.result(), tr.last_grad_norm)
+    np.testing.assert_allclose(got[True], got[False], rtol=1e-5)
+
+
 def test_beam_decoder_agrees_with_greedy_on_confident_outputs():
     """A width-1..16 prefix beam search returns the greedy transcript when every frame is confident."""
     from codes.decoder import BeamCTCDecoder, GreedyDecoder
