@@ -239,16 +239,20 @@ __global__ void conv2_split_prepare_kernel(const float* __restrict__ w, int mode
 }
 
 // d(out) (B, 32, 21, T) -> zero-bordered copy (B, 32, 41, T + 20): 10 rows and 10 columns of zeros on every side
-__global__ void conv2_pad_dout_kernel(const float* __restrict__ dy, int B, int T, float* __restrict__ dyp) {
-    const int TP = T + 20;
-    const size_t total = (size_t)B * 32 * 41 * TP;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int tc = (int)(i % TP);
-        const size_t r = i / TP;
-        const int fr = (int)(r % 41);
-        const size_t bc = r / 41;
-        const int t = tc - 10, fo = fr - 10;
-        dyp[i] = (t >= 0 && t < T && fo >= 0 && fo < 21) ? dy[(bc * 21 + fo) * T + t] : 0.f;
+// (one padded row per workgroup iteration: the row is decoded once with 32-bit arithmetic -- per element, three 64-bit
+// divisions made this copy of 32 MB a 57 us kernel on the chain of the backward pass)
+__global__ __launch_bounds__(256) void conv2_pad_dout_kernel(const float* __restrict__ dy, int B, int T,
+                                                             float* __restrict__ dyp) {
+    const int TP = T + 20, nrows = B * 32 * 41;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int bc = r / 41, fo = r - bc * 41 - 10;
+        float* dst = dyp + (size_t)r * TP;
+        if (fo < 0 || fo >= 21) {
+            for (int tc = threadIdx.x; tc < TP; tc += 256) dst[tc] = 0.f;
+        } else {
+            const float* src = dy + ((size_t)bc * 21 + fo) * T - 10;
+            for (int tc = threadIdx.x; tc < TP; tc += 256) dst[tc] = (tc >= 10 && tc < T + 10) ? src[tc] : 0.f;
+        }
     }
 }
 
@@ -378,7 +382,7 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
     int* tab = reinterpret_cast<int*>(ws);
     unsigned int* Wp[2] = {reinterpret_cast<unsigned int*>(ws) + 1024, reinterpret_cast<unsigned int*>(ws) + 1024 + img0};
     float* dyp = reinterpret_cast<float*>(ws) + 1024 + img0 + img1;
-    hipLaunchKernelGGL(conv2_pad_dout_kernel, dim3(2048), dim3(256), 0, st, d_out, B, T, dyp);
+    hipLaunchKernelGGL(conv2_pad_dout_kernel, dim3(B * 32 * 41 < 8192 ? B * 32 * 41 : 8192), dim3(256), 0, st, d_out, B, T, dyp);
     // ONE decision about the zero fill for both row-parity launches, made before the first of them runs
     bool zeroed = false;
     for (int par = 0; par < 2; ++par)
