@@ -238,8 +238,7 @@ class Trainer(object):
 
     def _forward_backward(self, inputs, loss_fn, hook):
         m = self.model
-        m._ensure_flat()
-        gflat = m.flat_grad()
+        state = {}
         # ONE fill of the whole flat gradient, on the side stream beside the forward pass (the step's first side-stream work:
         # everything the backward pass puts there, and the main stream through the w_hh_t_ready event, is ordered behind
         # it), instead of a fill in front of every split-K weight-gradient GEMM
@@ -250,6 +249,10 @@ class Trainer(object):
             # with a synchronisation the GPU idles until the first long kernel is enqueued, and the stream switch + fill cost
             # the host ~25 us there.  Still ahead of everything that writes the gradient: the side stream's own work follows
             # it in stream order, the main stream's through the w_hh_t_ready event recorded after it.)
+            # (the check that the parameters are still views of the flat buffers belongs here too: the conv block reads its
+            # weights through the modules, everything that relies on the flat layout -- the paired GRU weights, the gradients,
+            # the optimizer -- comes after this point)
+            gflat = state['gflat'] = m.flat_grad()           # (checks the flat layout itself)
             main = torch.cuda.current_stream()
             side = m._side_stream(gflat.device) if m.overlap_wgrad else None
             if side is not None:
@@ -260,7 +263,7 @@ class Trainer(object):
 
         acts, sv = m._forward_impl(inputs.contiguous().float(), training=True, need_grad=True, after_conv=fill)
         costs, d_acts = loss_fn(acts)
-        m._backward_impl(sv, d_acts, gflat, grad_ready=hook, prezeroed=prezero)
+        m._backward_impl(sv, d_acts, state['gflat'], grad_ready=hook, prezeroed=prezero)
         return costs, acts
 
     def _bucket_hook(self):

@@ -83,8 +83,8 @@ class BatchSpectrogram(object):
             offs.append(offs[-1] + n)
         frames = [1 + n // HOP for n in lens]
         t_max = max(frames)
-        offs_d = ops.upload_small(torch.tensor(offs, dtype=torch.int64), flat.device)
-        inputs = ops.spectrogram(flat, offs_d, t_max, self.normalize, self.eps)
+        # (the offsets stay on the host, in page-locked memory the two kernels read in place: ops.spectrogram)
+        inputs = ops.spectrogram(flat, torch.tensor(offs, dtype=torch.int64), t_max, self.normalize, self.eps)
         pct = torch.tensor([f / float(t_max) for f in frames], dtype=torch.float32)
         return inputs, pct
 
