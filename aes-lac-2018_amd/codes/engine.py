@@ -45,12 +45,13 @@ class PendingLoss(object):
 
     def __init__(self, trainer, host, done, bsz, scale):
         self.trainer, self.host, self.done, self.bsz, self.scale = trainer, host, done, bsz, scale
+        self.stream = torch.cuda.current_stream() if done is None else None   # the stream the step was queued on
         self._value = None
 
     def result(self):
         if self._value is None:
             if self.done is None:                 # the kernel wrote the slot itself: poll the memory
-                loss_sum, sumsq, timed_out, n_inf = ops.wait_step_stats(self.host)
+                loss_sum, sumsq, timed_out, n_inf = ops.wait_step_stats(self.host, stream=self.stream)
             else:
                 ops.spin_wait(self.done)
                 loss_sum, sumsq, timed_out, n_inf = self.host.tolist()
@@ -170,7 +171,13 @@ class Trainer(object):
             self.skip_n -= 1
             return 'Skipped'
         model = self.model
-        if not model.training:
+        # ``model.train()`` at the top of every step (codes/engine.py:51) -- which also returns the BatchNorm modules that
+        # ``_freeze_layers`` put in eval mode to training mode.  The recursive call costs ~60 us of host time with the GPU idle;
+        # the flags it would change are looked at instead (the model and its seven BatchNorm modules)
+        bns = self.__dict__.get('_bn_modules')
+        if bns is None:
+            bns = self._bn_modules = [m for m in model.modules() if hasattr(m, 'num_batches_tracked')]
+        if not model.training or not all(m.training for m in bns):
             model.train()
         t0 = time.time()
         inputs, targets, input_percentages, target_sizes = batch

@@ -236,6 +236,7 @@ class DeepSpeech(nn.Module):
                         break
             if ok:
                 return
+        self.__dict__.pop('_bn_walk', None)                  # a swapped sub-module: the cached BatchNorm list is stale
         order = self._flat_order()
         ok = self._flat_p is not None and len(order) == len(self._plist)
         if ok:
@@ -303,29 +304,46 @@ class DeepSpeech(nn.Module):
         assert t > 0, 'input too short for the conv stack'
         sv = {'t_in': t_in, 't1': t1, 't': t, 'bsz': bsz}
         c = self.conv
-        # fine-tuning with frozen conv layers keeps their BatchNorm in inference mode (training_utils.py:52-54,73)
+        # Each BatchNorm follows its OWN ``training`` flag, as torch's does.  The reference's ``_freeze_layers`` puts the
+        # BatchNorm modules of a frozen layer in eval mode once, at set-up (training_utils.py:52-54,73) -- and its update
+        # step calls ``model.train()`` at the top of EVERY step (codes/engine.py:51), which puts them back: under the
+        # reference's trainer a frozen conv block still normalises with batch statistics and keeps moving its running
+        # estimates (Trainer.update repeats that call).  A caller that drives forward_backward itself with
+        # ``model.conv[1].eval()`` gets inference-mode BatchNorm in the conv block; in the recurrent stack and the head only
+        # the all-training case exists.
         # (plain instance-dict lookups: a missing attribute on an nn.Module costs a failed walk through its parameter /
         # buffer / sub-module tables and an exception -- ~3 us each, ~30 of them here, at the top of a step with the GPU idle)
-        conv_frozen = c[1].__dict__.get('frozen_stats', False) or c[4].__dict__.get('frozen_stats', False)
-        conv_train = training and not conv_frozen
-        mods = self.__dict__.get('_bn_walk')
-        if mods is None:                                   # the module tree is static: walk it once
-            mods = self.__dict__['_bn_walk'] = list(self.rnns.modules()) + list(self.fc.modules())
-        for mod in mods:
-            if mod.__dict__.get('frozen_stats', False):
-                raise NotImplementedError('freezing BatchNorm statistics is supported for the conv block only')
+        c1_train = training and c[1].training
+        c4_train = training and c[4].training
+        if training:
+            mods = self.__dict__.get('_bn_walk')
+            if mods is None:                               # the module tree is static (_ensure_flat drops this on a swap)
+                mods = self.__dict__['_bn_walk'] = [m for m in list(self.rnns.modules()) + list(self.fc.modules())
+                                                    if isinstance(m, _BatchNormParams)]
+            for mod in mods:
+                if not mod.training:
+                    raise NotImplementedError('BatchNorm in inference mode inside a training step is supported for the '
+                                              'conv block only')
         self._tick('start')
         xt = ops.transpose_btf(x)                                                   # (B,161,T_in)
         y1 = ops.conv_fwd(1, xt, c[0].weight, c[0].bias, t_in)                      # (B,32,61,T1)
-        mi1 = ops.bn2d_stats(y1, c[1].running_mean, c[1].running_var, conv_train)
+        mi1 = ops.bn2d_stats(y1, c[1].running_mean, c[1].running_var, c1_train)
         a1 = ops.bn2d_apply_htanh(y1, mi1, c[1].weight, c[1].bias, layout_tbf=False)
         y2 = ops.conv_fwd(2, a1, c[3].weight, c[3].bias, t1)                        # (B,32,21,T)
-        mi2 = ops.bn2d_stats(y2, c[4].running_mean, c[4].running_var, conv_train)
+        mi2 = ops.bn2d_stats(y2, c[4].running_mean, c[4].running_var, c4_train)
         xin = ops.bn2d_apply_htanh(y2, mi2, c[4].weight, c[4].bias, layout_tbf=True)  # (T,B,672)
-        if conv_train:
+        if c1_train:
             c[1].num_batches_tracked += 1
+        if c4_train:
             c[4].num_batches_tracked += 1
-        sv['conv_frozen'] = conv_frozen
+        # a conv block with no trainable parameter (freeze_layers: ["conv"]): nothing upstream of the recurrent stack needs
+        # a gradient, whatever mode its BatchNorm runs in
+        sv['conv_frozen'] = need_grad and not (c[0].weight.requires_grad or c[0].bias.requires_grad or
+                                               c[1].weight.requires_grad or c[1].bias.requires_grad or
+                                               c[3].weight.requires_grad or c[3].bias.requires_grad or
+                                               c[4].weight.requires_grad or c[4].bias.requires_grad)
+        if need_grad and not (c1_train and c4_train) and not sv['conv_frozen']:
+            raise NotImplementedError('inference-mode BatchNorm in a conv block with trainable parameters has no backward here')
         sv.update(xt=xt, y1=y1, mi1=mi1, a1=a1, y2=y2, mi2=mi2)
         self._tick('conv block forward (transpose, conv1, conv2, 2 x BatchNorm + clip)')
         if after_conv is not None:

@@ -53,10 +53,6 @@ def get_model(model_dict):
     return DeepSpeech(**params)
 
 
-class _FrozenMarker(object):
-    """Modules whose BatchNorm must stay in inference mode are tagged so the model can honour it."""
-
-
 def _freeze_layers(model, freeze_layers):
     if freeze_layers is None:
         return model
@@ -68,7 +64,11 @@ def _freeze_layers(model, freeze_layers):
         if isinstance(target, torch.nn.Module):
             for m in target.modules():
                 if isinstance(m, _BatchNormParams):
-                    m.frozen_stats = True            # reference: BatchNorm of frozen layers put in eval mode (:52-54,73)
+                    # the reference puts the BatchNorm of a frozen LAYER (not of 'all', whose parameters() is neither a
+                    # Tensor nor a Module there: :66-67,72-74) in eval mode (:52-54,73) -- until the trainer's
+                    # ``model.train()`` at the top of the first step undoes it (codes/engine.py:51; Trainer.update)
+                    if name != 'all':
+                        m.eval()
             params = target.parameters()
         else:
             params = [target]

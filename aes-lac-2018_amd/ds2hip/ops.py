@@ -551,17 +551,50 @@ def arm_step_stats(slot):
     slot.view(torch.int64).fill_(STATS_SENTINEL)
 
 
-def wait_step_stats(slot, timeout_s=120.0):
-    """Poll a slot armed by ``arm_step_stats`` until the device has written all four values."""
+def _stats_timeout():
+    """Seconds the host waits for a step's statistics before giving up: ``DS2_STATS_TIMEOUT_S`` if set (``0`` / ``inf`` = no
+    limit); otherwise no limit inside a process group -- the statistics are queued behind the gradient all-reduce there, a
+    slow peer (rank 0 saving a checkpoint, uneven evaluation shards, a cold loader) is not an error, and the group's own
+    watchdog bounds the wait -- and 120 s for a single-GPU run."""
+    v = os.environ.get('DS2_STATS_TIMEOUT_S')
+    if v is not None:
+        t = float(v)
+        return None if t <= 0 or t == float('inf') else t
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return None
+    return 120.0
+
+
+def wait_step_stats(slot, timeout_s='default', stream=None):
+    """Poll a slot armed by ``arm_step_stats`` until the device has written all four values.
+
+    While waiting, the stream the step was queued on is queried from time to time: a device fault raises as the HIP error it
+    is (not as a time-out minutes later), and a stream that has DRAINED without the slot being written -- the statistics
+    kernel never ran -- raises at once.  ``timeout_s``: None = wait without limit, 'default' = ``_stats_timeout()``."""
     import time
     words = slot.view(torch.int64).numpy()
-    t_end = None
+    t0, next_query, every = None, 0.0, 0.02
     while (words == STATS_SENTINEL).any():
         time.sleep(0)                             # (hands the GIL to a loader / pin-memory thread that wants it)
-        if t_end is None:
-            t_end = time.time() + timeout_s
-        elif time.time() > t_end:
-            raise RuntimeError('the step\'s statistics never arrived in host memory (%.0f s)' % timeout_s)
+        now = time.time()
+        if t0 is None:
+            t0, next_query = now, now + every
+            if timeout_s == 'default':
+                timeout_s = _stats_timeout()
+            continue
+        if now < next_query:
+            continue
+        every = min(every * 2, 1.0)
+        next_query = now + every
+        st = stream if stream is not None else torch.cuda.current_stream()
+        if st.query():                            # (raises the pending HIP error of a faulted device)
+            time.sleep(0.001)
+            if (words == STATS_SENTINEL).any():
+                raise RuntimeError('the stream has run everything queued on it and the step\'s statistics were never '
+                                   'written to host memory')
+        if timeout_s is not None and now - t0 > timeout_s:
+            raise RuntimeError('the step\'s statistics never arrived in host memory (%.0f s; DS2_STATS_TIMEOUT_S)' % timeout_s)
     return slot.tolist()
 
 

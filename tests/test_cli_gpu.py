@@ -203,3 +203,60 @@ def test_finetune_cli_en_checkpoint_to_pt_br_head(tmp_path):
     model, _, _, target_t = load_model(str(tmp_path / 'ft' / 'ft' / 'model_ckpt_1.pth'), return_transforms=True,
                                        data_dir=str(tmp_path))
     assert model._num_classes == 43 and len(target_t[0].label_encoder.classes_) == 43
+
+
+def test_freeze_config_cli_from_an_en_checkpoint(tmp_path):
+    """``train.py scripts/pt_BR-finetune-freeze.json --continue-from <EN ckpt>`` (reference README.md:193, the 30.80 % row of
+    BASELINE.md) with the shipped file's own ``model`` / ``training.finetune`` / ``optimizer`` / ``scheduler`` values (only the
+    model size, epochs and batch size are shrunk): ``finetune: true`` makes the run call ``finetune_model`` -- the one caller of
+    ``_freeze_layers`` (training_utils.py:57-91) -- and start as a NEW run: epoch 0, iteration 0, fresh optimizer and scheduler
+    (train.py:142-167).  The conv block's parameters come out bit-identical; its BatchNorm running statistics do move, because
+    the update step's ``model.train()`` (codes/engine.py:51) returns the frozen BatchNorm to training mode -- the reference's
+    literal behaviour (tests/test_host2_cpu.py::test_reference_freeze_leaves_batchnorm_training_under_its_update_step)."""
+    _corpus(tmp_path)
+    common = ['--data-dir', str(tmp_path), '--train-manifest', str(tmp_path / 'train.csv'), '--val-manifest',
+              str(tmp_path / 'val.csv'), '--local', '--checkpoint', '--num-workers', '0']
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), str(tmp_path / 'tiny.json')] + common +
+                         ['--save-folder', str(tmp_path / 'en')], capture_output=True, text=True, env=dict(os.environ),
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    en_ckpt = tmp_path / 'en' / 'tiny' / 'model_ckpt_2.pth'
+    en = torch.load(str(en_ckpt), map_location='cpu', weights_only=False)
+    cfg = json.load(open(os.path.join(ROOT, 'scripts', 'pt_BR-finetune-freeze.json')))
+    assert cfg['training']['finetune'] is True and cfg['model']['freeze_layers'] == ['conv'] and cfg['model']['langs'] == ['en']
+    cfg['model']['params'] = {'rnn_hidden_size': 32, 'num_rnn_layers': 2}
+    cfg['training'].update(num_epochs=1, batch_size=3)
+    (tmp_path / 'freeze.json').write_text(json.dumps(cfg))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), str(tmp_path / 'freeze.json')] + common +
+                         ['--continue-from', str(en_ckpt), '--save-folder', str(tmp_path / 'fr')], capture_output=True,
+                         text=True, env=dict(os.environ), timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    log = out.stderr + out.stdout
+    conv_keys = ['conv.0.weight', 'conv.0.bias', 'conv.1.weight', 'conv.1.bias', 'conv.3.weight', 'conv.3.bias',
+                 'conv.4.weight', 'conv.4.bias']
+    n_frozen = sum(en['state_dict'][k].numel() for k in conv_keys)
+    assert 'Freezed {} parameters'.format(n_frozen) in log
+    assert 'Changing the last FC layer' not in log           # langs: ["en"]: the 29-way head stays
+    assert 'Start epoch:' not in log and 'Epoch: [1][1/2]' in log
+    ft = torch.load(str(tmp_path / 'fr' / 'pt_BR-finetune-freeze' / 'model_ckpt_1.pth'), map_location='cpu',
+                    weights_only=False)
+    assert ft['epoch'] == 1 and ft['iteration'] == 2 and len(ft['val_metrics']['cer']) == 1
+    for k in conv_keys:
+        assert torch.equal(ft['state_dict'][k], en['state_dict'][k]), k
+    moved = [k for k, v in en['state_dict'].items()
+             if k not in conv_keys and 'running' not in k and 'num_batches' not in k and not torch.equal(v, ft['state_dict'][k])]
+    assert len(moved) == len([k for k in en['state_dict'] if 'running' not in k and 'num_batches' not in k]) - len(conv_keys)
+    # BatchNorm of the frozen block: training mode under the update step (2 more batches seen, statistics moved)
+    assert int(ft['state_dict']['conv.1.num_batches_tracked']) == int(en['state_dict']['conv.1.num_batches_tracked']) + 2
+    assert not torch.equal(ft['state_dict']['conv.1.running_mean'], en['state_dict']['conv.1.running_mean'])
+    # a fresh optimizer and scheduler: the freeze file's lr annealed once by ITS gamma, not the EN run's annealed lr
+    assert ft['optimizer']['param_groups'][0]['lr'] == pytest.approx(3e-4 * 0.99, rel=1e-12)
+    assert en['optimizer']['param_groups'][0]['lr'] == pytest.approx(3e-4 * 0.909090909 ** 2, rel=1e-9)
+    # frozen parameters (the first eight of model.parameters(): the conv block) have no momentum that could move them
+    state = ft['optimizer']['state']
+    params = ft['optimizer']['param_groups'][0]['params']
+    assert len(params) == len([k for k in en['state_dict'] if 'running' not in k and 'num_batches' not in k])
+    for i in params[:8]:
+        buf = state.get(i, {}).get('momentum_buffer')
+        assert buf is None or not bool(buf.any())
+    assert bool(state[params[8]]['momentum_buffer'].any())

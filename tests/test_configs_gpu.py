@@ -174,7 +174,9 @@ def test_config4_finetuned_pt_br_head_full_size_with_beam():
     losses = [trainer.update(batch) for _ in range(4)]
     assert all(np.isfinite(v) and v > 0 for v in losses) and losses[-1] < losses[0], losses
     assert torch.equal(model.conv[0].weight, before)                       # frozen block untouched
-    assert int(model.conv[1].num_batches_tracked) == 0                      # its BatchNorm stayed in inference mode
+    # ... and its BatchNorm ran in training mode: the trainer's per-step model.train() (codes/engine.py:51) undoes the
+    # eval() of _freeze_layers, as in the reference
+    assert int(model.conv[1].num_batches_tracked) == 4 and model.conv[1].training
     whole = _eval_grouping_invariance(model, batch[0], [(0, 10), (10, 32)])
     assert whole.shape == (32, 746, 43)
     labels = json.load(open(os.path.join(ROOT, 'data', 'labels.pt_BR.json')))

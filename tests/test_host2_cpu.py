@@ -86,6 +86,57 @@ def test_configs_and_model_factory():
     assert abs(sch.gamma - 0.909090909) < 1e-12
     assert expand_values({'a': ['{x}/b', {'c': '{x}'}]}, x='r') == {'a': ['r/b', {'c': 'r'}]}
 
+# Every leaf value of the eight shipped configs, as /root/reference/scripts/<same name>.json has it (a literal table: the
+# reference tree does not travel).  `training.finetune` of pt_BR-finetune-freeze is `true` there
+# (/root/reference/scripts/pt_BR-finetune-freeze.json:12): it is what makes train.py call finetune_model, the only caller of
+# _freeze_layers, and start from epoch 0 with a fresh optimizer (train.py:142-167).
+_SGD = {'optimizer.name': 'SGD', 'optimizer.params.lr': 3e-4, 'optimizer.params.momentum': 0.9,
+        'optimizer.params.nesterov': True, 'scheduler.name': 'ExponentialLR'}
+_PT = dict(_SGD, **{'training.num_epochs': 100, 'training.batch_size': 32, 'training.max_norm': 400, 'training.augment': True,
+                    'scheduler.params.gamma': 0.99})
+SHIPPED_CONFIGS = {
+    'example': dict(_PT, **{'model.name': 'example', 'model.freeze_layers': 'all', 'model.langs': ['pt_BR'],
+                            'model.map_fc': 'map_en-pt_BR.json', 'model.params.rnn_hidden_size': 800,
+                            'training.finetune': False, 'training.task_weights': [1],
+                            'optimizer.per_layer_lr': [['base'], ['fc', 3e-3]]}),
+    'librispeech-from_scratch': dict(_SGD, **{'model.name': 'librispeech-from_scratch', 'model.langs': ['en'],
+                                              'training.num_epochs': 15, 'training.batch_size': 10, 'training.max_norm': 400,
+                                              'training.augment': False, 'scheduler.params.gamma': 0.909090909}),
+    'pt_BR-finetune-accents-map-fc': dict(_PT, **{'model.name': 'pt_BR-finetune-accents-map-fc', 'model.langs': ['pt_BR'],
+                                                  'model.map_fc': 'map_en-pt_BR.json', 'training.finetune': True}),
+    'pt_BR-finetune-accents-random-fc': dict(_PT, **{'model.name': 'pt_BR-finetune-accents-random-fc',
+                                                     'model.langs': ['pt_BR'], 'training.finetune': True}),
+    'pt_BR-finetune-freeze': dict(_PT, **{'model.name': 'pt_BR-finetune-freeze', 'model.freeze_layers': ['conv'],
+                                          'model.langs': ['en'], 'training.finetune': True}),
+    'pt_BR-finetune': dict(_PT, **{'model.name': 'pt_BR-finetune', 'model.langs': ['en'], 'training.finetune': False}),
+    'pt_BR-from_scratch-accents': dict(_PT, **{'model.name': 'pt_BR-from_scratch-accents', 'model.langs': ['pt_BR'],
+                                               'training.finetune': False}),
+    'pt_BR-from_scratch': dict(_PT, **{'model.name': 'pt_BR-from_scratch', 'model.langs': ['en']}),
+}
+
+
+def _leaves(d, prefix=''):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_leaves(v, prefix + k + '.'))
+        else:
+            out[prefix + k] = v
+    return out
+
+
+def test_shipped_configs_hold_the_reference_values():
+    names = sorted(f[:-5] for f in os.listdir(os.path.join(ROOT, 'scripts')) if f.endswith('.json'))
+    assert names == sorted(SHIPPED_CONFIGS)
+    for name, want in SHIPPED_CONFIGS.items():
+        got = _leaves(json.load(open(os.path.join(ROOT, 'scripts', name + '.json'))))
+        assert got == want, (name, {k: (got.get(k), want.get(k)) for k in set(got) | set(want) if got.get(k) != want.get(k)})
+        for k, v in want.items():                                  # 400 vs 400.0, true vs 1 would compare equal
+            assert type(got[k]) is type(v), (name, k)
+    if os.path.isdir('/root/reference/scripts'):                   # in the build container: the table against the files
+        for name, want in SHIPPED_CONFIGS.items():
+            assert _leaves(json.load(open('/root/reference/scripts/%s.json' % name))) == want, name
+
 
 def test_finetune_surgery_and_freeze():
     from codes.utils import training_utils as tu
@@ -101,8 +152,43 @@ def test_finetune_surgery_and_freeze():
     assert torch.equal(new_w[2], old_w[3]) and torch.equal(new_w[0], old_w[0])      # 'A': EN row 3 -> PT row 2
     assert float(new_w[30].detach().abs().max()) < 0.1                                       # unmapped rows ~ N(0, 0.01)
     assert not any(p.requires_grad for p in model.conv.parameters())
-    assert model.conv[1].frozen_stats and all(p.requires_grad for p in model.rnns.parameters())
+    # BatchNorm of the frozen layer in eval mode (training_utils.py:52-54,73) -- until the next model.train(), which the
+    # reference's update step calls before every forward pass (codes/engine.py:51)
+    assert not model.conv[1].training and not model.conv[4].training and model.fc[0].module[0].training
+    assert all(p.requires_grad for p in model.rnns.parameters())
+    model.train()
+    assert model.conv[1].training and not any(p.requires_grad for p in model.conv.parameters())
     assert 'fc.0.module.1.weight' in model.state_dict() and model.state_dict()['fc.0.module.1.weight'].shape[0] == 43
+
+
+def test_reference_freeze_leaves_batchnorm_training_under_its_update_step():
+    """What ``freeze_layers`` does to BatchNorm in the reference, on stock torch modules (and, in the build container, on the
+    reference's own ``DeepSpeech``): ``_freeze_layers`` applies ``batch_norm_eval_mode`` to the layer
+    (training_utils.py:52-54,73), and ``_update`` calls ``model.train()`` before every forward pass (codes/engine.py:51) --
+    ``Module.train`` recurses, so the frozen layer's BatchNorm normalises with batch statistics and moves its running
+    estimates during training.  The product does the same (Trainer.update), see test_fused_step_with_param_groups_and_frozen_conv."""
+    nets = []
+    from oracle.model import OracleDeepSpeech
+    nets.append(OracleDeepSpeech(rnn_hidden_size=16, num_rnn_layers=1))
+    if os.path.isdir('/root/reference/codes'):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('ref_model_for_freeze', '/root/reference/codes/model.py')
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+        nets.append(ref.DeepSpeech(rnn_hidden_size=16, num_rnn_layers=1))
+    for net in nets:
+        def batch_norm_eval_mode(m):
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.eval()
+        net.conv.apply(batch_norm_eval_mode)
+        for p in net.conv.parameters():
+            p.requires_grad = False
+        assert not net.conv[1].training
+        net.train()                                              # codes/engine.py:51
+        assert net.conv[1].training and net.conv[4].training
+        before = net.conv[1].running_mean.clone()
+        net(torch.randn(2, 60, 161))
+        assert int(net.conv[1].num_batches_tracked) == 1 and not torch.equal(net.conv[1].running_mean, before)
 
 
 def test_checkpoint_roundtrip(tmp_path):

@@ -284,6 +284,30 @@ def test_deferred_readback_gives_the_same_steps(frozen_conv):
                 assert float((d > 2e-6).float().mean()) <= 0.01
 
 
+def test_statistics_wait_reports_a_drained_stream_and_honours_its_timeout(monkeypatch):
+    """The host's poll of the page-locked statistics slot (ops.wait_step_stats): a slot nobody writes is reported as soon as
+    the stream has drained (not after the time-out); the time-out comes from DS2_STATS_TIMEOUT_S, is 120 s single-GPU and
+    unlimited inside a process group (the statistics queue behind the gradient all-reduce: a slow peer is not an error)."""
+    import time
+    from ds2hip import ops
+    slot = torch.empty(4, dtype=torch.float64).pin_memory()
+    ops.arm_step_stats(slot)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match='never written'):
+        ops.wait_step_stats(slot)
+    assert time.time() - t0 < 5.0
+    monkeypatch.delenv('DS2_STATS_TIMEOUT_S', raising=False)
+    assert ops._stats_timeout() == 120.0
+    monkeypatch.setenv('DS2_STATS_TIMEOUT_S', '7.5')
+    assert ops._stats_timeout() == 7.5
+    monkeypatch.setenv('DS2_STATS_TIMEOUT_S', '0')
+    assert ops._stats_timeout() is None
+    monkeypatch.delenv('DS2_STATS_TIMEOUT_S')
+    monkeypatch.setattr(torch.distributed, 'is_initialized', lambda: True)
+    assert ops._stats_timeout() is None
+
+
 def test_step_statistics_readback_paths_agree(monkeypatch):
     """The step's one readback two ways: the statistics kernel writing the trainer's page-locked slot itself (the default;
     the host polls the memory) and the round-3 path (device buffer, non-blocking copy, polled event; DS2_STATS_DIRECT=0).
@@ -365,8 +389,13 @@ def test_edge_shapes_against_oracle(bsz, t_in, label_lens):
 
 def test_fused_step_with_param_groups_and_frozen_conv():
     """Fine-tuning shape of the reference (pt_BR-finetune-freeze.json + per-layer learning rates): conv block frozen
-    (its BatchNorm in inference mode, no gradient, no update), rnns and fc in separate groups with their own learning
-    rates -- still on the fused clip + SGD pass, and equal to torch on the oracle."""
+    (no gradient, no update), rnns and fc in separate groups with their own learning rates -- still on the fused clip +
+    SGD pass, and equal to torch on the oracle.
+
+    The frozen block's BatchNorm: ``_freeze_layers`` puts it in eval mode (training_utils.py:52-54,73) and the reference's
+    update step calls ``model.train()`` before every forward pass (codes/engine.py:51), which puts it back -- so under the
+    trainer it normalises with BATCH statistics and keeps updating its running estimates.  The oracle side below does
+    literally that (eval at set-up, ``train()`` per step)."""
     from codes.engine import Trainer
     from codes.utils.training_utils import _freeze_layers, get_per_params_lr
     from codes.utils.io_utils import AttrDict
@@ -377,8 +406,12 @@ def test_fused_step_with_param_groups_and_frozen_conv():
     model.load_state_dict(seeded_state_dict(oracle, 31))
     model.to('cuda')
     _freeze_layers(model, ['conv'])
+    assert not model.conv[1].training and not model.conv[4].training and model.rnns[1].batch_norm.module.training
     for p in oracle.conv.parameters():
         p.requires_grad_(False)
+    for m in oracle.conv.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()                                             # batch_norm_eval_mode, training_utils.py:52-54
     conf = AttrDict({'per_layer_lr': [['rnns', 2e-2], ['fc', 5e-3], ['base']]})
     opt = torch.optim.SGD(get_per_params_lr(model, conf), lr=1e-2, momentum=0.9, nesterov=True)
     opt_o = torch.optim.SGD([{'params': list(oracle.rnns.parameters()), 'lr': 2e-2},
@@ -393,8 +426,7 @@ def test_fused_step_with_param_groups_and_frozen_conv():
         labels = torch.from_numpy(rng.integers(1, 29, size=sum(label_lens)).astype(np.int32))
         pct = torch.ones(3, dtype=torch.float32)
         sizes = torch.tensor(label_lens, dtype=torch.int32)
-        oracle.train()
-        oracle.conv.eval()                                   # frozen modules keep BatchNorm in inference mode
+        oracle.train()                                       # codes/engine.py:51 -- the frozen BatchNorm is training again
         logits = oracle(x)
         out_sizes = (pct * logits.shape[1]).int()
         loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), labels.long(), out_sizes.long(), sizes.long(),
@@ -407,6 +439,50 @@ def test_fused_step_with_param_groups_and_frozen_conv():
         assert abs(got - float(loss.item())) <= 2e-4 * abs(float(loss.item()))
         for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
             np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), atol=5e-5, err_msg='%s step %d' % (k, step))
+    assert model.conv[1].training and int(model.conv[1].num_batches_tracked) == 2
+    for k in ('conv.1.running_mean', 'conv.1.running_var', 'conv.4.running_mean', 'conv.4.running_var'):
+        np.testing.assert_allclose(model.state_dict()[k].cpu().numpy(), oracle.state_dict()[k].numpy(), rtol=2e-5, atol=1e-6,
+                                   err_msg=k)
+
+
+def test_conv_batchnorm_held_in_inference_mode_inside_a_training_pass():
+    """A caller that drives the model itself (not through the trainer, whose ``model.train()`` per step undoes it) can hold
+    the frozen conv block's BatchNorm in inference mode: ``model.conv[i].eval()`` under ``model.train()``, torch's own
+    semantics.  Logits and the gradients of the trainable layers against the oracle in the same state."""
+    kwargs = dict(rnn_hidden_size=32, num_rnn_layers=2, num_classes=29)
+    oracle = OracleDeepSpeech(**kwargs)
+    sd = seeded_state_dict(oracle, 33)
+    rng = np.random.default_rng(33)
+    for k in ('conv.1.running_mean', 'conv.4.running_mean'):
+        sd[k] = torch.from_numpy(rng.uniform(-0.2, 0.2, size=32).astype(np.float32))
+    for k in ('conv.1.running_var', 'conv.4.running_var'):
+        sd[k] = torch.from_numpy(rng.uniform(0.5, 2.0, size=32).astype(np.float32))
+    oracle.load_state_dict(sd)
+    model = _build(kwargs)
+    model.load_state_dict(sd)
+    model.to('cuda')
+    for net in (model, oracle):
+        net.train()
+        for p in net.conv.parameters():
+            p.requires_grad_(False)
+        net.conv[1].eval()
+        net.conv[4].eval()
+    x = torch.from_numpy(seeded_inputs(44, 3, 90))
+    dl = torch.from_numpy(rng.standard_normal((3, 40, 29)).astype(np.float32))
+    want = oracle(x)
+    (want * dl).sum().backward()
+    got = model(x.to('cuda'))
+    (got * dl.to('cuda')).sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), atol=2e-4)
+    assert int(model.conv[1].num_batches_tracked) == 0
+    np.testing.assert_array_equal(model.conv[1].running_mean.cpu().numpy(), sd['conv.1.running_mean'].numpy())
+    for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        if q.requires_grad:
+            scale = max(float(q.grad.abs().max()), 1e-6)
+            np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.numpy(), atol=2e-4 * scale, err_msg=k)
+    model.rnns[1].batch_norm.module.eval()
+    with pytest.raises(NotImplementedError):
+        model(x.to('cuda'))
 
 
 @pytest.mark.parametrize('optimizer', ['sgd_fused', 'sgd_autograd'])
