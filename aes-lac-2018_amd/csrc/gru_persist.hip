@@ -73,6 +73,7 @@ constexpr unsigned long long SPIN_TICKS = 500000000ull;  // 5 s of the 100 MHz r
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NSHARD = 8;  // arrival counters per direction (workgroup x -> shard x % 8), each on its own 128-B line:
                            // 100 arrivals on ONE word serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
 struct SyncWs {            // lives in caller-provided device memory: zeroed ONCE by the caller when it is allocated (and
@@ -2210,6 +2211,239 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent4_kernel(float* __
     if (tid == 0) leave_kernel(sync);
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// Forward recurrence, the ROW deal (round 5): the 16 blocks of a v_mfma_f32_4x4x1_16b_f32 are 16 different ROW GROUPS of the
+// workgroup's 3 UNITS <= 64 gate rows, ALL at the same k (A = h at ONE k, broadcast to the 16 blocks: CBSZ = 4, ABID picks the
+// block of the A register that holds that k), so an instruction retires 1 k x 64 gate rows x 4 batch rows -- the same 256
+// multiply-adds as in the deals above, KW = H / 8 instructions per wave (100 at H = 800: what the k-balanced deal issues) --
+// and a wave's accumulator holds COMPLETE sums over the wave's KW columns: 8 partials per output (one per wave) instead of
+// 32 (wave x lane row).  What that removes from the part of a step that has no hardware floor (last MFMA -> payload stores):
+// 12 of a lane's 16 partial-sum stores to LDS (30.7 -> 7.7 KB per step through the 64-B/clk store path), three quarters of
+// the gate threads' reads (six ds_read_b128 -> three ds_read_b64) and of their adds.
+// Lane (b, li): B operand = w_hh row R = 4 b + li = lane (gate R / UNITS, unit R % UNITS) at k = KW wave + n for instruction n
+// (KW registers, resident).  A operand: column n = 64 j + 4 b' + c of the wave sits in component c of dwordx4 load j, block
+// b': lane (b', i) holds h[k = KW wave + 64 j + 4 b' + c][batch row i], instruction n reads register (j, c) with ABID = b'.
+// Exchange ring slot: [wave 8][load NLD][block 16][rows][4] floats (the k-balanced deal's size; lane l of a wave-load reads
+// bytes 16 l .. 16 l + 15 of one contiguous KB; blocks past the wave's KW columns are neither written nor loaded).  Four
+// consecutive units of one batch row are 16 contiguous bytes: the first of their four gate threads stores them as ONE
+// 16-byte write-through store (and ONE 16-byte canary two slots ahead) -- 20 + 20 store instructions of a sixteenth of the
+// lanes per step where the deals above issue 80 + 80 dword stores (a dword sc1 store costs ~6x a dwordx4's time per byte:
+// MI355X_MICROARCH.md, stores of each flavour), and every 64-byte segment of a slot is written by ONE workgroup.
+// Speculative hand-off, one batch quad per workgroup, as gru_fwd_persistent4_kernel<.., PROTO = 2>.
+// ----------------------------------------------------------------------------------------------------------
+#ifndef DS2_FWD5_CHAINS
+#define DS2_FWD5_CHAINS 4        // independent accumulation chains per wave (joined with NCH - 1 vector adds per batch row)
+#endif
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v) {   // lane l of a 16-lane row <- lane l + N (0 past the row)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xF, 0xF, true));
+}
+template <int KW, int UNITS, int P>
+__global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                       float* __restrict__ hout,
+                                                                       const float* __restrict__ w_hh,
+                                                                       SyncWs* __restrict__ sync, float* __restrict__ ring,
+                                                                       int T, int B, int H, int dbg, int spec) {
+    constexpr int ROWS = 3 * UNITS;                      // gate rows of the workgroup (<= 64)
+    constexpr int NLD = (KW + 63) / 64;                  // dwordx4 loads per lane
+    constexpr int NCH = DS2_FWD5_CHAINS;
+    constexpr int NSLOT = 4, CAHEAD = 2;
+    static_assert(ROWS <= 64 && KW % 4 == 0 && UNITS % 4 == 0 && NLD <= 2 && (NWP * 64) / (4 * UNITS) >= 4, "row deal: shape");
+    // [batch row 4][gate row 64][8 partials, rotated by (row >> 2) so that the 32 lanes of a store hit 32 banks]
+    __shared__ __attribute__((aligned(16))) float red5[4 * 64 * NWP];
+    __shared__ int abort_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, bpart = blockIdx.z;
+    const int nslice = gridDim.x;
+    const int j0 = blockIdx.x * UNITS;
+    const int blk = lane >> 2, li = lane & 3;
+    const int bper = (B + P - 1) / P;
+    const int b0 = bpart * bper;
+    const int nb = min(bper, B - b0);                   // <= 4 (the launcher)
+    if (nb <= 0) {
+        if (tid == 0) leave_kernel(sync);
+        return;
+    }
+    const int slot_floats = NWP * NLD * 64 * nb;
+    float* my_ring = ring + (size_t)(dir * P + bpart) * NSLOT * ((size_t)NWP * NLD * 64 * bper);
+    if (tid == 0) abort_flag = 0;
+
+    // resident weights: row `lane` of the workgroup's gate rows, the wave's KW columns
+    float wK[KW];
+    {
+        const int gate = lane / UNITS, unit = j0 + lane % UNITS;
+        const float* row = (lane < ROWS && unit < H) ? w_hh + ((size_t)dir * 3 * H + (size_t)gate * H + unit) * H + KW * wave : nullptr;
+#pragma unroll
+        for (int n4 = 0; n4 < KW / 4; ++n4) {
+            const f32x4u v = row ? *reinterpret_cast<const f32x4u*>(row + 4 * n4) : f32x4u{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wK[4 * n4 + c] = v[c];
+        }
+    }
+    // gate role: 4 threads (gpart) per (local batch row nn, unit jj), each adds 2 of the 8 partials of the three gate rows;
+    // the 16 lanes of a row = 4 consecutive units (UNITS and the slices' first units are multiples of 4) of ONE batch row
+    const int gpart = tid & 3, jj = (tid >> 2) % UNITS, nn = (tid >> 2) / UNITS;
+    const int gj = j0 + jj;
+    const bool mine = nn < nb && gj < H;
+    const bool storer = mine && (tid & 15) == 0;        // hands off units gj .. gj + 3 of batch row nn (H % 4 == 0: all exist)
+    float hp = 0.f;
+    unsigned int* shards = &sync->arrive[dir][bpart][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    // where units gj .. gj + 3 (= columns k of every consumer) sit in a ring slot: wave kw, column n -> load n / 64, block n / 4 % 16
+    int hoff = 0;
+    const u32x4 can4 = {CANARY_BITS, CANARY_BITS, CANARY_BITS, CANARY_BITS};
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, NSLOT * slot_floats * 4, 0x00020000);
+    if (storer) {
+        const int kw = gj / KW, n = gj % KW;
+        hoff = ((((kw * NLD + (n >> 6)) * 16 + ((n >> 2) & 15)) * nb + nn) * 4) * 4;      // bytes
+#pragma unroll
+        for (int sl = 0; sl < CAHEAD; ++sl) store_sc1_b128(rs_w, sl * slot_floats * 4 + hoff, can4);   // (an earlier launch's payload)
+    }
+    wait_vmcnt0();
+    __syncthreads();
+    // one counted rendezvous per launch: every producer's start-up canaries are in place before anybody reads
+    if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0 && !wait_arrivals(shards, 1, nslice, lane, &sync->error) && lane == 0) abort_flag = 1;
+    __syncthreads();
+    if (abort_flag) return;
+
+    int scur = 0, sprev = NSLOT - 1;
+    int spec_delay = spec & 0xFF, spec_clean = 0, nretry = 0;
+    // this lane's byte offset inside a slot for load j (rows past the batch and blocks past the wave's columns load nothing)
+    int loff[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j)
+        loff[j] = (li < nb && 64 * j + 4 * blk < KW) ? ((((wave * NLD + j) * 16 + blk) * nb + li) * 4) * 4 : OOB_OFFSET;
+    float* const red_w = red5 + lane * NWP + ((wave + (lane >> 2)) & (NWP - 1));
+    // gate threads: partials 2 gpart, 2 gpart + 1 (rotated positions: any two, the four gparts cover all eight) of gate g
+    const float* const red_r = red5 + (nn * 64 + jj) * NWP + 2 * gpart;
+    // saved-activation / pre-activation element offsets (this thread's unit and batch row; advanced per step)
+    const long long tstep = dir == 0 ? 1 : -1;
+    const int t_first = dir == 0 ? 0 : T - 1;
+    const long long dG = tstep * (long long)B * 6 * H, dO = tstep * (long long)B * H, dN = tstep * (long long)B * 2 * H;
+    size_t of_g = (((size_t)t_first * B + b0 + nn) * 2 + dir) * 3 * H + gj;
+    size_t of_o = (((size_t)dir * T + t_first) * B + b0 + nn) * H + gj;
+    size_t of_n = (((size_t)t_first * B + b0 + nn) * 2 + dir) * H + gj;
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
+    if (mine) {
+        gi_r = G[of_g];
+        gi_z = G[of_g + H];
+        gi_n = G[of_g + 2 * H];
+    }
+    for (int s = 0; s < T; ++s) {
+        DS2_WTICK(0);
+        // where this step's payload and the canary two slots ahead go (scalar arithmetic, ahead of the matrix phase)
+        const int pay_off = scur * slot_floats * 4 + hoff, can_off = ((scur + CAHEAD) & (NSLOT - 1)) * slot_floats * 4 + hoff;
+        if (s > 0) {
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
+            f32x4 bf[1][NLD];
+            for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
+            auto load_frag = [&](int, int j) { bf[0][j] = LOAD_HANDOFF(rs_x, loff[j]); };
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                if (DS2_STAGE_GAP > 0 && j > 0) __builtin_amdgcn_s_sleep(DS2_STAGE_GAP);
+                load_frag(0, j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            DS2_WTICK(2);
+            f32x4 acc[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bool racc = false;
+            static_for<0, NLD>([&](auto j_tag) {
+                constexpr int j = decltype(j_tag)::value;
+                validate_fragments<1, NLD, 0, j, j + 1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag, nretry,
+                                                        &racc, j == NLD - 1);
+                if (j == 0) DS2_WTICK(3);
+                // component-major: consecutive instructions read different A registers and different accumulators
+                static_for<0, 64>([&](auto m_tag) {
+                    constexpr int m = decltype(m_tag)::value, c = m >> 4, bb = m & 15, n = 64 * j + 4 * bb + c;
+                    if constexpr (n < KW)
+                        acc[m % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[0][j][c], wK[n], acc[m % NCH], 4, bb, 0);
+                });
+            });
+            DS2_WTICK(4);
+            f32x4 sum = acc[0];
+            if constexpr (NCH == 2) sum = acc[0] + acc[1];
+            if constexpr (NCH == 4) sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red_w[i * 64 * NWP] = sum[i];
+        }
+        DS2_WTICK(5);
+        __syncthreads();
+        DS2_WTICK(6);
+        // the previous step's stores (a step old) are complete before this step's payload goes out (see CANARY_BITS)
+        wait_vmcnt0();
+        DS2_WTICK(7);
+        float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
+        if (s > 0) {
+            if (nn < 4) {
+                const f32x2 pr = *reinterpret_cast<const f32x2*>(red_r);
+                const f32x2 pz = *reinterpret_cast<const f32x2*>(red_r + UNITS * NWP);
+                const f32x2 pn = *reinterpret_cast<const f32x2*>(red_r + 2 * UNITS * NWP);
+                gh_r = pr[0] + pr[1];
+                gh_z = pz[0] + pz[1];
+                gh_n = pn[0] + pn[1];
+            }
+            gh_r = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_r));
+            gh_z = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_z));
+            gh_n = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_n));
+        }
+        float h = 0.f, sv_a = 0.f;
+        if (mine) {
+            const float r = fast_sigmoid(gi_r + gh_r);
+            const float z = fast_sigmoid(gi_z + gh_z);
+            const float n = fast_tanh(gi_n + r * gh_n);
+            h = (1.f - z) * n + z * hp;
+            hp = h;
+            sv_a = gpart == 1 ? r : (gpart == 2 ? z : n);
+        }
+        {
+            // the row's four units (lanes 0, 4, 8, 12 of the 16) to its first lane: one 16-byte payload, one 16-byte canary
+            const float pay = not_canary(h);
+            const f32x4 v = {pay, dpp_row_shl<4>(pay), dpp_row_shl<8>(pay), dpp_row_shl<12>(pay)};
+            if (storer) {
+                // (fault-injection builds: workgroup 0 'loses' its payload of step 2 -> its consumers time out, not hang)
+                const bool lose = DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
+                if (!lose) store_sc1_b128(rs_w, pay_off, __builtin_bit_cast(u32x4, v));
+                store_sc1_b128(rs_w, can_off, can4);
+            }
+        }
+        const int aborted = abort_flag;                 // (issued here, consumed at the end of the step)
+        // the next step's gate pre-activations, behind this step's payload (see DS2_GI_PREFETCH)
+        const size_t og = of_g, oo = of_o, on = of_n;
+        of_g += dG;
+        of_o += dO;
+        of_n += dN;
+        if (mine && s + 1 < T) {
+            gi_r = G[of_g];
+            gi_z = G[of_g + H];
+            gi_n = G[of_g + 2 * H];
+        }
+        if (spec & (1 << 17)) wait_vmcnt0();            // self-timed: see spec_timing()
+        sprev = scur;
+        scur = (scur + 1) & (NSLOT - 1);
+        DS2_WTICK(8);
+        __syncthreads();
+        DS2_WTICK(9);
+        if (mine) {   // saved activations: read by later launches only, off the critical path
+            if (gpart == 0) {
+                hout[oo] = h;
+                ghn[on] = gh_n;
+            } else {
+                G[og + (size_t)(gpart - 1) * H] = sv_a;
+            }
+        }
+        DS2_WTICK(10);
+        if (aborted) return;
+    }
+    DS2_RETRY_FLUSH(nretry);
+    if (tid == 0) leave_kernel(sync);
+}
+
 // Speculative protocol: how long a wave waits (units of s_sleep 1 = 64 clocks) before a step's first hand-off loads, and
 // between re-loads.  A failed attempt costs a full round trip and adds polling traffic from 1600 waves, so the first attempt
 // is timed to land just after the slowest producer's payload; measured optimum (tools/gru_sweep.py, B = 4 .. 12): the forward
@@ -2431,6 +2665,18 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
     return false;
 }
 
+// the row deal (gru_fwd_persistent5_kernel): three batch parts of one quad each, 20 units per workgroup, H = 8 KW
+template <int KW>
+bool launch_fwd_persistent5(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
+                            int H, int dbg, hipStream_t st) {
+    constexpr int UNITS = 20, P = 3;
+    dim3 grid(ds2_cdiv(H, UNITS), 2, P), block(NWP * 64);
+    auto kern = &gru_fwd_persistent5_kernel<KW, UNITS, P>;
+    if (!grid_is_coresident(kern, grid, 0)) return false;
+    hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, spec_timing(0));
+    return true;
+}
+
 template <int NRG, int PROTO, int NP = NRG / 2>
 bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                             SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
@@ -2608,8 +2854,14 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
         // three parts, one batch quad each, speculative hand-off (B = 9 .. 12): 20-unit slices on 240 CUs when they fit
         const char* wide = getenv("DS2_GRU_FWD_WIDE");
         if (parts == 3 && !two && proto != 0 && (wide ? wide[0] == '1' : true) && H % 4 == 0 &&
-            6 * ds2_cdiv(H, 20) <= max_persistent_wgs() && 6 * ds2_cdiv(H, 20) > 6 * ds2_cdiv(H, 24))
-            ok = launch_fwd_persistent4<3, 1, 2, 5>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+            6 * ds2_cdiv(H, 20) <= max_persistent_wgs() && 6 * ds2_cdiv(H, 20) > 6 * ds2_cdiv(H, 24)) {
+            // the row deal where it is built (H = 800: 100 columns per wave); DS2_GRU_FWD_ROWS = 0: the k-balanced deal (A/B timing)
+            const char* rows = getenv("DS2_GRU_FWD_ROWS");
+            if (H == 800 && bper <= 4 && !(rows && rows[0] == '0'))
+                ok = launch_fwd_persistent5<100>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+            else
+                ok = launch_fwd_persistent4<3, 1, 2, 5>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+        }
         else
         if (parts == 1) ok = two ? DS2_FWD4_GO(1, 2) : DS2_FWD4_GO(1, 1);
         else if (parts == 2) ok = two ? DS2_FWD4_GO(2, 2) : DS2_FWD4_GO(2, 1);
