@@ -1716,6 +1716,292 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// Backward recurrence, the BROADCAST deal (round 5; B = 9 .. 12: three batch parts of one quad, speculative hand-off).
+//
+// gru_bwd_persistent4_kernel gives every one of an instruction's 16 blocks a different k of the SAME 4 units, so each of a
+// wave's NRG accumulators holds 16 partial sums per output: 2 DPP adds per value fold them inside the lane rows -- 40 / 48 /
+// 56 DPP adds and 20 / 24 / 28 stores of a quarter of the lanes per wave and step (NRG = 5 / 6 / 7), between the last MFMA
+// and the pre-gate barrier: 0.35 us on the waves that finish last (tools/gru_wave_timing.py).  Here the operands swap
+// roles, as in the forward kernels: A = d(gates) (4 batch rows at one k; broadcast inside a group of blocks: CBSZ / ABID),
+// B = weights, a different ROW GROUP of 4 units in every block of a group:
+//   set A, CBSZ = 2: the 4 blocks of lane row g = row groups 0 .. 3 at k sub-index g                   (4 k per instruction)
+//   set B, CBSZ = 1 (NRG >= 6): block pairs = row groups 4, 5 at k sub-index (g, q >> 1)               (8 k per instruction)
+//   set C, CBSZ = 0 (NRG odd): all 16 blocks = the last row group at k sub-index (g, q)               (16 k per instruction)
+// -- the same 5 / 6 / 7 instructions per 16 k, the same resident weights (20 NRG registers), the same exchange ring (lane
+// (block, batch row) loads 4 consecutive k) -- and set A's partial sums over k sub-indices sit in different lane ROWS, which
+// the gate threads add anyway with the 8 waves (32 partials per output, as before): no fold for 16 of the units, one DPP
+// add per value for set B, two for set C (8 / 12 / 20 DPP adds per wave and step), and every lane stores its own 4 values.
+// The gate role is spread over 4 threads per (unit, batch row): each adds 8 of the 32 partials (two ds_read_b128, not
+// eight), two rotate-adds inside the 16-lane row give every one of the four the sum, all four do the (cheap) gate math, and
+// the hand-off and saved-activation stores are dealt out among them: a storing lane issues 2 16-byte write-through stores
+// (one gate's payload for 4 units + its canary) instead of 6, every lane ONE saved-activation store instead of 4.
+// ----------------------------------------------------------------------------------------------------------
+constexpr int RED5_PITCH = NWP * 4 + 4;
+template <int N>
+__device__ __forceinline__ float dpp_row_ror_add(float v) {   // v + (the value N lanes up the 16-lane row, cyclically)
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+template <int NGI, int NRG>
+__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent5_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                       const float* __restrict__ hout,
+                                                                       const float* __restrict__ d_out,
+                                                                       const float* __restrict__ w_hh_t,
+                                                                       SyncWs* __restrict__ sync, float* __restrict__ ring,
+                                                                       int T, int B, int H, int dbg, int spec) {
+    static_assert(NRG >= 5 && NRG <= 7, "broadcast deal: 20, 24 or 28 units per workgroup");
+    constexpr int NPART = 3, UNITS = 4 * NRG;
+    constexpr bool HASB = NRG >= 6, HASC = (NRG & 1) != 0;
+    constexpr int NSLOT = 4, CAHEAD = 2, SIGW = NWP - 1;
+    // [value = (row group, unit 4, batch row 4)][RED5_PITCH: 32 partials = (wave, lane row), rotated by 4 ((unit >> 1) + 2 rg)
+    // so that the 32 lanes of a store instruction hit 16 banks twice]
+    __shared__ __attribute__((aligned(16))) float red5[NRG * 16 * RED5_PITCH];
+    __shared__ int abort_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
+    const int j0 = blockIdx.x * UNITS;
+    const int blk = lane >> 2, li = lane & 3, g = lane >> 4, q = (lane >> 2) & 3;
+    const int K = 3 * H;
+    const int bper = (B + NPART - 1) / NPART;
+    const int b0 = part * bper;
+    const int nb = min(bper, B - b0);                   // <= 4 (the launcher)
+    const int ng = (K + 63) >> 6;
+    const int slot_floats = ng * 64 * nb;
+    float* my_ring = ring + (size_t)(dir * NPART + part) * NSLOT * ((size_t)ng * 64 * bper);
+    if (nb <= 0) {
+        if (tid == 0) leave_kernel(sync);
+        return;
+    }
+    if (tid == 0) abort_flag = 0;
+
+    // resident weights (B operands), component e of a register quad = k + e
+    f32x4 wA[NGI][4], wB[HASB ? NGI : 1][2], wC[HASC ? NGI : 1];
+    {
+        auto wrow = [&](int rg) {
+            const int unit = j0 + 4 * rg + li;
+            return unit < H ? w_hh_t + ((size_t)dir * H + unit) * K : nullptr;
+        };
+        const float* rowA = wrow(q);
+        const float* rowB = wrow(4 + (q & 1));
+        const float* rowC = wrow(NRG - 1);
+        auto ld = [&](const float* row, int k) {
+            return (row && k < K) ? *reinterpret_cast<const f32x4*>(row + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+#pragma unroll
+        for (int gi = 0; gi < NGI; ++gi) {
+            const int k0 = 64 * (wave + NWP * gi);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wA[gi][a] = ld(rowA, k0 + 16 * g + 4 * a);
+            if constexpr (HASB) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wB[gi][a] = ld(rowB, k0 + 8 * (blk >> 1) + 4 * a);
+            }
+            if constexpr (HASC) wC[gi] = ld(rowC, k0 + 4 * blk);
+        }
+    }
+    // gate role: lane = (unit in quad u4, gpart gp) inside a 16-lane row; a row = one unit quad (= row group) of one batch row
+    const int u4 = tid & 3, gp = (tid >> 2) & 3, uq = (tid >> 4) % NRG, nn = (tid >> 4) / NRG;
+    const int gb = b0 + nn, gj = j0 + 4 * uq + u4;
+    const bool gate_ok = (nn < nb) && (gj < H);
+    float dhz = 0.f;
+    unsigned int* shards = &sync->arrive[dir][part][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    // hand-off: lane u4 == 0 of gpart gp < 3 stores gate gp of the quad's four units (k index of unit j in gate gp is gp H + j)
+    const bool storer = gate_ok && u4 == 0 && gp < 3;
+    const int hok = (gp < 3 ? gp : 0) * H + gj;
+    const int ho = (nn & 3) * 4 + (hok >> 2) * (nb * 4) + (hok & 3);          // floats inside a slot (one batch quad)
+    const u32x4 can4 = {CANARY_BITS, CANARY_BITS, CANARY_BITS, CANARY_BITS};
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, NSLOT * slot_floats * 4, 0x00020000);
+    if (storer) {                                       // slot 0 (and 1) may hold an earlier launch's payload
+#pragma unroll
+        for (int sl = 0; sl < CAHEAD; ++sl) store_sc1_b128(rs_w, (sl * slot_floats + ho) * 4, can4);
+    }
+    wait_vmcnt0();
+    __syncthreads();
+    // one counted rendezvous per launch (see gru_bwd_persistent4_kernel)
+    if (tid == SIGW * 64) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == SIGW && !wait_arrivals(shards, 1, nslice, lane, &sync->error) && lane == 0) abort_flag = 1;
+    __syncthreads();
+    if (abort_flag) return;
+    int scur = 0, sprev = NSLOT - 1;
+    int spec_delay = spec & 0xFF, spec_clean = 0, nretry = 0;
+
+    // this lane's byte offsets inside a slot (rows past the batch and k past K load nothing) and its partial-sum positions
+    int loff[NGI];
+#pragma unroll
+    for (int gi = 0; gi < NGI; ++gi) {
+        const int gg = wave + NWP * gi;
+        loff[gi] = (64 * gg + 4 * blk < K && li < nb) ? (((gg * 16 + blk) * nb + li) * 4) * 4 : OOB_OFFSET;
+    }
+    auto red_at = [&](int rg, int unit, int part32) {   // value (rg, unit, batch 0), partial position part32 (rotated)
+        return red5 + ((rg * 4 + unit) * 4) * RED5_PITCH + ((part32 + 4 * ((unit >> 1) + 2 * rg)) & 31);
+    };
+    float* const redA = red_at(q, li, wave * 4 + g);
+    float* const redB = red_at(4 + (q & 1), li, wave * 4 + g);
+    float* const redC = red_at(NRG - 1, li, wave * 4 + g);
+    const float* const red_r = red5 + ((uq * 4 + u4) * 4 + nn) * RED5_PITCH + 8 * gp;
+
+    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
+    const long long tstep = dir == 0 ? -1 : 1;
+    const long long dG = tstep * B * 6 * H, dD = tstep * B * H, dN = tstep * B * 2 * H;
+    const int t_first = dir == 0 ? T - 1 : 0;
+    size_t of_g = (((size_t)t_first * B + gb) * 2 + dir) * 3 * H + gj;            // G[of_g + g H]: gate g of step t
+    size_t of_d = ((size_t)t_first * B + gb) * H + gj;                            // d_out
+    size_t of_n = (((size_t)t_first * B + gb) * 2 + dir) * H + gj;                // ghn
+    size_t of_h = (((size_t)dir * T + t_first + tstep) * B + gb) * H + gj;        // hout of the step BEFORE t in forward time order
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? T - 1 - s : s;
+        // next != 0: the step after this one (its offsets = this step's + the constant strides)
+        auto early_loads = [&](int next) {
+            dh = r = z = n = gn = hpv = 0.f;
+            if (gate_ok) {
+                const int tt = t + (next ? (int)tstep : 0);
+                const bool has_prev = dir == 0 ? (tt > 0) : (tt < T - 1);
+                const size_t g0 = of_g + (next ? dG : 0);
+                dh = d_out[of_d + (next ? dD : 0)];
+                r = G[g0];
+                z = G[g0 + H];
+                n = G[g0 + 2 * H];
+                gn = ghn[of_n + (next ? dN : 0)];
+                if (has_prev) hpv = hout[of_h + (next ? dD : 0)];
+            }
+        };
+        DS2_WTICK(0);
+        if (s == 0) early_loads(0);
+        DS2_WTICK(1);
+        if (s > 0) {
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
+            f32x4 bf[1][NGI];
+            for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
+            auto load_frag = [&](int, int gi) { bf[0][gi] = LOAD_HANDOFF(rs_x, loff[gi]); };
+            constexpr int SPLIT = (3 * NGI + 4) / 5;       // two stages: k groups 0 .. SPLIT - 1, then the rest (DS2_STAGED_BWD = 2)
+#pragma unroll
+            for (int gi = 0; gi < NGI; ++gi) {
+                if (DS2_STAGE_GAP_BWD > 0 && gi == SPLIT && NGI > 1) __builtin_amdgcn_s_sleep(DS2_STAGE_GAP_BWD);
+                load_frag(0, gi);
+            }
+            __builtin_amdgcn_sched_barrier(0);             // every load out before the first MFMA
+            DS2_WTICK(2);
+            f32x4 accA[4], accB[2], accC;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) accA[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            accB[0] = accB[1] = accC = f32x4{0.f, 0.f, 0.f, 0.f};
+            bool racc = false;
+            constexpr int NSTG = NGI > 1 ? 2 : 1;
+            static_for<0, NSTG>([&](auto st_tag) {
+                constexpr int st = decltype(st_tag)::value;
+                constexpr int G0 = st == 0 ? 0 : SPLIT, G1 = (NSTG == 1 || st == 1) ? NGI : SPLIT;
+                validate_fragments<1, NGI, 0, G0, G1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag, nretry,
+                                                      &racc, st == NSTG - 1);
+                if (st == 0) DS2_WTICK(3);
+#pragma unroll
+                for (int gi = G0; gi < G1; ++gi)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        accA[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[0][gi][e], wA[gi][0][e], accA[0], 2, 0, 0);
+                        accA[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[0][gi][e], wA[gi][1][e], accA[1], 2, 1, 0);
+                        if constexpr (HASB) accB[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[0][gi][e], wB[gi][0][e], accB[0], 1, 0, 0);
+                        accA[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[0][gi][e], wA[gi][2][e], accA[2], 2, 2, 0);
+                        accA[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[0][gi][e], wA[gi][3][e], accA[3], 2, 3, 0);
+                        if constexpr (HASB) accB[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[0][gi][e], wB[gi][1][e], accB[1], 1, 1, 0);
+                        if constexpr (HASC) accC = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[0][gi][e], wC[gi][e], accC, 0, 0, 0);
+                    }
+            });
+            DS2_WTICK(4);
+            // D register i = batch row i; lane (g, q, li): set A -> unit li of row group q, k sub-index g
+            const f32x4 sa = (accA[0] + accA[1]) + (accA[2] + accA[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) redA[i * RED5_PITCH] = sa[i];
+            if constexpr (HASB) {                          // k sub-indices (g, q >> 1): one DPP add, lanes 8 .. 15 of a row hold the sum
+                const f32x4 sb = accB[0] + accB[1];
+                float fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fb[i] = dpp_row_shr_add<8>(sb[i]);
+                if (q >= 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) redB[i * RED5_PITCH] = fb[i];
+                }
+            }
+            if constexpr (HASC) {                          // k sub-indices (g, q): two DPP adds, lanes 12 .. 15 hold the sum
+                float fc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fc[i] = dpp_row_shr_add<8>(dpp_row_shr_add<4>(accC[i]));
+                if (q == 3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) redC[i * RED5_PITCH] = fc[i];
+                }
+            }
+        }
+        DS2_WTICK(5);
+        __syncthreads();
+        DS2_WTICK(6);
+        float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
+        {
+            float part = 0.f;
+            if (s > 0 && nn < 4) {                        // this gpart's 8 of the 32 partials
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(red_r), p1 = *reinterpret_cast<const f32x4*>(red_r + 4);
+                const f32x4 ps = p0 + p1;
+                part = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            }
+            part = dpp_row_ror_add<8>(dpp_row_ror_add<4>(part));      // the four gparts of a unit sit 4 lanes apart
+            if (gate_ok) {
+                dh += part + dhz;
+                const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+                const float dz_pre = dh * (hpv - n) * z * (1.f - z);
+                const float dr_pre = dn_pre * gn * r * (1.f - r);
+                dhz = dh * z;
+                sv_r = dr_pre;
+                sv_z = dz_pre;
+                sv_n = dn_pre;
+                sv_g = dn_pre * r;
+            }
+        }
+        {
+            // the quad's four units of ONE gate (gpart gp's) to its first lane: one 16-byte payload, one 16-byte canary
+            const float mine_v = not_canary(gp == 0 ? sv_r : (gp == 1 ? sv_z : sv_g));
+            f32x4 v;
+            v[0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0x00, 0xF, 0xF, true));
+            v[1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0x55, 0xF, 0xF, true));
+            v[2] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0xAA, 0xF, 0xF, true));
+            v[3] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0xFF, 0xF, 0xF, true));
+            // the stores of the PREVIOUS step (a step old) are complete before this step's payload goes out (see CANARY_BITS)
+            wait_vmcnt0();
+            DS2_WTICK(7);
+            if (storer) {
+                // (fault-injection builds: workgroup 0 'loses' its payload of step 2 -> its consumers time out, not hang)
+                const bool lose = DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
+                if (!lose) store_sc1_b128(rs_w, (scur * slot_floats + ho) * 4, __builtin_bit_cast(u32x4, v));
+                store_sc1_b128(rs_w, (((scur + CAHEAD) & (NSLOT - 1)) * slot_floats + ho) * 4, can4);
+            }
+        }
+        const int aborted = abort_flag;                 // (issued here, consumed at the end of the step)
+        const size_t og = of_g, on = of_n;
+        if (s + 1 < T) early_loads(1);                  // the next step's, behind this step's payload
+        if (spec & (1 << 17)) wait_vmcnt0();            // self-timed: see spec_timing()
+        sprev = scur;
+        scur = (scur + 1) & (NSLOT - 1);
+        DS2_WTICK(8);
+        __syncthreads();
+        DS2_WTICK(9);
+        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: one plain store per lane, off the critical path
+            if (gp == 3) ghn[on] = sv_g;
+            else G[og + (size_t)gp * H] = gp == 0 ? sv_r : (gp == 1 ? sv_z : sv_n);
+        }
+        of_g += dG;
+        of_d += dD;
+        of_n += dN;
+        of_h += dD;
+        DS2_WTICK(10);
+        if (aborted) return;
+    }
+    DS2_RETRY_FLUSH(nretry);
+    if (tid == SIGW * 64) leave_kernel(sync);
+}
+
+// ----------------------------------------------------------------------------------------------------------
 // Forward recurrence on v_mfma_f32_4x4x1_16b_f32 with A-operand broadcast (CBSZ / ABID; tools/mfma4x4_bcast_probe.hip:
 // blocks are grouped 2^CBSZ at a time and every block of a group takes its A rows from the group's block ABID).
 //
@@ -2376,6 +2662,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
         __syncthreads();
         DS2_WTICK(6);
         // the previous step's stores (a step old) are complete before this step's payload goes out (see CANARY_BITS)
+        // (it costs nothing measurable: 2.34 -> 2.34 us per step at B = 10 without it)
         wait_vmcnt0();
         DS2_WTICK(7);
         float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
@@ -2427,6 +2714,8 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
         sprev = scur;
         scur = (scur + 1) & (NSLOT - 1);
         DS2_WTICK(8);
+        // (with the partial sums double-buffered this barrier is not needed for correctness -- and the step is 0.03-0.05 us
+        // SLOWER without it, B = 10 / 12: 2.37 / 2.44 against 2.31-2.34 / 2.41: it keeps the eight waves' next hand-off loads together)
         __syncthreads();
         DS2_WTICK(9);
         if (mine) {   // saved activations: read by later launches only, off the critical path
@@ -2666,10 +2955,10 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
 }
 
 // the row deal (gru_fwd_persistent5_kernel): three batch parts of one quad each, 20 units per workgroup, H = 8 KW
-template <int KW>
+template <int KW, int P = 3>
 bool launch_fwd_persistent5(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
                             int H, int dbg, hipStream_t st) {
-    constexpr int UNITS = 20, P = 3;
+    constexpr int UNITS = 20;
     dim3 grid(ds2_cdiv(H, UNITS), 2, P), block(NWP * 64);
     auto kern = &gru_fwd_persistent5_kernel<KW, UNITS, P>;
     if (!grid_is_coresident(kern, grid, 0)) return false;
@@ -2703,6 +2992,29 @@ bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float
         DS2_BWD4_CASE(5)
     }
 #undef DS2_BWD4_CASE
+    return false;
+}
+
+// the broadcast deal (gru_bwd_persistent5_kernel): three batch parts of one quad each, speculative hand-off
+template <int NRG>
+bool launch_bwd_persistent5(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
+                            SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
+    const int opts[] = {1, 2, 3, 5};
+    const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
+    dim3 grid(ds2_cdiv(H, 4 * NRG), 2, 3), block(NWP * 64);
+#define DS2_BWD5_CASE(K)                                                                                         \
+    case K:                                                                                                      \
+        if (!grid_is_coresident(&gru_bwd_persistent5_kernel<K, NRG>, grid, 0)) return false;                     \
+        hipLaunchKernelGGL((gru_bwd_persistent5_kernel<K, NRG>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, sync, ring, \
+                           T, B, H, dbg, spec_timing(1));                                                         \
+        return true;
+    switch (ngi) {
+        DS2_BWD5_CASE(1)
+        DS2_BWD5_CASE(2)
+        DS2_BWD5_CASE(3)
+        DS2_BWD5_CASE(5)
+    }
+#undef DS2_BWD5_CASE
     return false;
 }
 
@@ -2862,6 +3174,8 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
             else
                 ok = launch_fwd_persistent4<3, 1, 2, 5>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
         }
+        // (the row deal with two batch parts -- 20 units, 160 workgroups -- measured at B = 8: 2.30 us per step against 2.15 for
+        // the 16-unit k-balanced form on 200: its 48 gate rows fill 12 of the 16 blocks, the row deal would issue 100 MFMAs for 75)
         else
         if (parts == 1) ok = two ? DS2_FWD4_GO(1, 2) : DS2_FWD4_GO(1, 1);
         else if (parts == 2) ok = two ? DS2_FWD4_GO(2, 2) : DS2_FWD4_GO(2, 1);
@@ -2963,12 +3277,21 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
         const char* w = getenv("DS2_GRU_BWD_WIDE");
         if (w && w[0] >= '0' && w[0] <= '2') want = w[0] == '0' ? 52 : (w[0] == '1' ? 82 : 0);
         const int g20 = 6 * ds2_cdiv(H, 20), g24 = 6 * ds2_cdiv(H, 24), g28 = 6 * ds2_cdiv(H, 28);
-        if (g20 <= max_persistent_wgs() && g20 > g24 && cus - g20 >= want)
-            ok = launch_bwd_persistent4<5, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);   // 240 workgroups
-        else if (cus - g24 >= want || g28 >= g24)
-            ok = launch_bwd_persistent4<6, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);   // 204
-        else
-            ok = launch_bwd_persistent4<7, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);   // 174
+        // the broadcast deal (gru_bwd_persistent5_kernel) where a part is one batch quad and H a multiple of 4;
+        // DS2_GRU_BWD_BCAST = 0: the 16-k-blocks deal (A/B timing)
+        // (measured stand-alone at B = 10, us per step, 16-k-blocks -> broadcast deal: 28 units 3.02-3.05 -> 2.92, 24 units
+        // 2.79-2.81 -> 2.72, 20 units 2.61-2.64 -> 2.67-2.69: the widest form keeps the old deal unless DS2_GRU_BWD_BCAST = 1)
+        const char* bc = getenv("DS2_GRU_BWD_BCAST");
+        const bool bcast = H % 4 == 0 && ds2_cdiv(B, 3) <= 4 && !(bc && bc[0] == '0');
+        if (g20 <= max_persistent_wgs() && g20 > g24 && cus - g20 >= want)                                     // 240 workgroups
+            ok = (bcast && bc && bc[0] == '1') ? launch_bwd_persistent5<5>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
+                       : launch_bwd_persistent4<5, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+        else if (cus - g24 >= want || g28 >= g24)                                                               // 204
+            ok = bcast ? launch_bwd_persistent5<6>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
+                       : launch_bwd_persistent4<6, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+        else                                                                                                    // 174
+            ok = bcast ? launch_bwd_persistent5<7>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
+                       : launch_bwd_persistent4<7, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     }
     else if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
