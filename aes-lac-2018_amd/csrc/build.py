@@ -23,8 +23,37 @@ OUT = os.path.join(PKG, 'ds2hip', 'libds2hip.so')
 OUT_FI = os.path.join(PKG, 'ds2hip', 'libds2hip_faultinject.so')
 OBJ = os.path.join(HERE, 'build')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', HERE,
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-I', os.path.join(ROOT, 'include'), '-I', HERE, '-I', OBJ,
          '-Wall', '-Wno-unused-function'] + os.environ.get('DS2_HIPCC_EXTRA', '').split()   # e.g. -DDS2_TIMING=1
+
+
+def source_id():
+    """sha256 over the library's sources (every .hip / .h of csrc/ and include/ds2hip.h, names and contents) -- the value
+    ``ds2_build_id()`` of a library built from this tree returns.  ds2hip/lib.py computes the same digest when it loads the
+    library and refuses a binary that was built from other sources (the .so files travel to the GPU box beside the sources
+    and are cached by mtime here: nothing else ties a binary to the tree it is benchmarked with)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(HERE) if f.endswith('.hip') or f.endswith('.h'))
+    for f in files + [os.path.join(ROOT, 'include', 'ds2hip.h')]:
+        path = f if os.path.isabs(f) else os.path.join(HERE, f)
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
+        h.update(b'\0')
+    return h.hexdigest()[:32]
+
+
+def _stamp_build_id():
+    """csrc/build/build_id.h = #define DS2_BUILD_ID "<source_id()>", rewritten only when the digest changes (api.hip, the one
+    file that includes it, is then recompiled by the mtime rule)."""
+    os.makedirs(OBJ, exist_ok=True)
+    path = os.path.join(OBJ, 'build_id.h')
+    text = '#define DS2_BUILD_ID "%s"\n' % source_id()
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, 'w') as f:
+            f.write(text)
+    return path
 
 
 def _newer(src, dst, deps):
@@ -92,6 +121,7 @@ def build_variant(name, flags, force=False):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
+    id_header = _stamp_build_id()
     srcs = sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
     deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
     deps.append(os.path.join(ROOT, 'include', 'ds2hip.h'))
@@ -101,7 +131,7 @@ def build(force=False, verbose=False):
         src = os.path.join(HERE, s)
         obj = os.path.join(OBJ, s[:-4] + '.o')
         objs.append(obj)
-        if force or _newer(src, obj, deps):
+        if force or _newer(src, obj, deps + ([id_header] if s == 'api.hip' else [])):
             jobs.append([HIPCC] + FLAGS + ['-c', src, '-o', obj])
     fi_src = os.path.join(HERE, 'gru_persist.hip')
     fi_obj = os.path.join(OBJ, 'gru_persist_faultinject.o')

@@ -1871,7 +1871,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent5_kernel(float* __
         DS2_WTICK(0);
         if (s == 0) early_loads(0);
         DS2_WTICK(1);
-        if (s > 0) {
+        if (s > 0 && !DS2_DBG(dbg, 2)) {                  // (ablation bits 2 / 2048 / 4096: see gru_fwd_persistent5_kernel)
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
                 my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
             f32x4 bf[1][NGI];
@@ -1894,9 +1894,11 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent5_kernel(float* __
             static_for<0, NSTG>([&](auto st_tag) {
                 constexpr int st = decltype(st_tag)::value;
                 constexpr int G0 = st == 0 ? 0 : SPLIT, G1 = (NSTG == 1 || st == 1) ? NGI : SPLIT;
-                validate_fragments<1, NGI, 0, G0, G1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag, nretry,
-                                                      &racc, st == NSTG - 1);
+                if (!DS2_DBG(dbg, 2048))
+                    validate_fragments<1, NGI, 0, G0, G1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag,
+                                                          nretry, &racc, st == NSTG - 1);
                 if (st == 0) DS2_WTICK(3);
+                if (!DS2_DBG(dbg, 4096))
 #pragma unroll
                 for (int gi = G0; gi < G1; ++gi)
 #pragma unroll
@@ -1979,7 +1981,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent5_kernel(float* __
         }
         const int aborted = abort_flag;                 // (issued here, consumed at the end of the step)
         const size_t og = of_g, on = of_n;
-        if (s + 1 < T) early_loads(1);                  // the next step's, behind this step's payload
+        if (s + 1 < T && !DS2_DBG(dbg, 8192)) early_loads(1);   // the next step's, behind this step's payload (bit 8192: see the forward kernel)
         if (spec & (1 << 17)) wait_vmcnt0();            // self-timed: see spec_timing()
         sprev = scur;
         scur = (scur + 1) & (NSLOT - 1);
@@ -2622,7 +2624,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
         DS2_WTICK(0);
         // where this step's payload and the canary two slots ahead go (scalar arithmetic, ahead of the matrix phase)
         const int pay_off = scur * slot_floats * 4 + hoff, can_off = ((scur + CAHEAD) & (NSLOT - 1)) * slot_floats * 4 + hoff;
-        if (s > 0) {
+        // (ablation bits, fault-injection / timing builds only -- results WRONG: 2 = no hand-off loads and no MFMAs (the step's
+        // skeleton), 2048 = loads issued but not validated (nobody waits for anybody: matrix phase + skeleton), 4096 = no MFMAs
+        // (hand-off + skeleton); bench.py's floor leg times them)
+        if (s > 0 && !DS2_DBG(dbg, 2)) {
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
                 my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
             f32x4 bf[1][NLD];
@@ -2641,10 +2646,12 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
             bool racc = false;
             static_for<0, NLD>([&](auto j_tag) {
                 constexpr int j = decltype(j_tag)::value;
-                validate_fragments<1, NLD, 0, j, j + 1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag, nretry,
-                                                        &racc, j == NLD - 1);
+                if (!DS2_DBG(dbg, 2048))
+                    validate_fragments<1, NLD, 0, j, j + 1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag,
+                                                            nretry, &racc, j == NLD - 1);
                 if (j == 0) DS2_WTICK(3);
                 // component-major: consecutive instructions read different A registers and different accumulators
+                if (!DS2_DBG(dbg, 4096))
                 static_for<0, 64>([&](auto m_tag) {
                     constexpr int m = decltype(m_tag)::value, c = m >> 4, bb = m & 15, n = 64 * j + 4 * bb + c;
                     if constexpr (n < KW)
@@ -2705,7 +2712,9 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
         of_g += dG;
         of_o += dO;
         of_n += dN;
-        if (mine && s + 1 < T) {
+        // (ablation bit 8192: keep step 0's pre-activations -- with bits 2 + 8192 the step is so short that these loads' HBM
+        // latency, which a full step never waits for, would be what the skeleton measurement shows)
+        if (mine && s + 1 < T && !DS2_DBG(dbg, 8192)) {
             gi_r = G[of_g];
             gi_z = G[of_g + H];
             gi_n = G[of_g + 2 * H];

@@ -21,6 +21,7 @@ _Z = ctypes.c_size_t
 SIGNATURES = {
     'ds2_last_error': (ctypes.c_char_p, []),
     'ds2_version': (_I, []),
+    'ds2_build_id': (ctypes.c_char_p, []),
     'ds2_spectrogram_ws_bytes': (_Z, [_I, _I]),
     'ds2_spectrogram_fwd': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _P]),
     'ds2_pcm16_to_float': (_I, [_P, _Z, _F, _P, _P]),
@@ -99,8 +100,27 @@ def load():
             # signatures change between revisions without a change of symbol name: a stale binary would mis-pass arguments
             raise RuntimeError('%s is ABI revision %d, this binding is written against %d (include/ds2hip.h DS2_ABI_VERSION) '
                                '-- rebuild it: python aes-lac-2018_amd/csrc/build.py' % (LIB_PATH, have, ABI_VERSION))
+        _check_build_id(lib)
         _lib = lib
     return _lib
+
+
+def _check_build_id(lib):
+    """The loaded binary must have been built from the sources beside it (csrc/build.py: source_id() is stamped into the
+    library and recomputed here).  Skipped where there are no sources (a binary-only install) or with DS2_SKIP_BUILD_CHECK=1."""
+    if os.environ.get('DS2_SKIP_BUILD_CHECK') == '1':
+        return
+    build_py = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'csrc', 'build.py')
+    if not os.path.exists(build_py):
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ds2_build_for_id', build_py)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    have, want = lib.ds2_build_id().decode(), mod.source_id()
+    if have != want:
+        raise RuntimeError('%s was built from other sources than the ones beside it (build id %s, tree %s) -- rebuild it: '
+                           'python aes-lac-2018_amd/csrc/build.py' % (LIB_PATH, have, want))
 
 
 def _ptr(x):

@@ -296,6 +296,81 @@ def gru_pass_roofline(model, bsz, t):
     return out
 
 
+def recurrence_floor(bsz, t, hid, dev, spare_below):
+    """LIVE latency-model floor of one recurrence time step, measured in this run by ablating the SHIPPED kernels' own source:
+    the fault-injection build of the library (csrc/build.py: the release objects with gru_persist.hip compiled with
+    -DDS2_FAULT_INJECT=1, no timing stamps) honours DS2_GRU_DBG bits that switch phases of a step off -- 2: no hand-off loads
+    and no MFMAs (what is left is the step's skeleton: barriers, LDS round trip, gate math, stores), 2048: loads issued but
+    never validated, so nobody waits for anybody (matrix phase + skeleton), 4096: no MFMAs (hand-off + skeleton), 8192: no
+    prefetch of the next step's saved activations (a full step never waits for those HBM loads; a shortened one would).  The
+    hand-off and the matrix phase overlap in the shipped kernels (a fragment is multiplied as soon as it has landed), so
+    floor = max(hand-off, matrix) + skeleton.  Results of the ablated launches are wrong by construction; nothing reads them."""
+    import ctypes
+    path = os.path.join(ROOT, 'aes-lac-2018_amd', 'ds2hip', 'libds2hip_faultinject.so')
+    if not os.path.exists(path) or bsz < 9 or bsz > 12 or hid != 800:
+        return None
+    L = ctypes.CDLL(path)
+    L.ds2_gru_sync_ws_bytes.restype = ctypes.c_size_t
+    L.ds2_gru_sync_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.ds2_gru_bidir_fwd_persistent.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
+    L.ds2_gru_bidir_bwd_persistent_ex.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    ws = torch.zeros(L.ds2_gru_sync_ws_bytes(bsz, hid) // 4 + 64, dtype=torch.int32, device=dev)
+    w = ((torch.rand(2, 3 * hid, hid, device=dev) * 2 - 1) / hid ** 0.5)
+    wt = w.transpose(1, 2).contiguous()
+    gates = 0.1 * torch.randn(t, bsz, 2, 3 * hid, device=dev)
+    ghn = torch.zeros(t, bsz, 2, hid, device=dev)
+    hout = torch.zeros(2, t, bsz, hid, device=dev)
+    d_out = 0.01 * torch.randn(t, bsz, hid, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    saved = {k: os.environ.get(k) for k in ('DS2_GRU_DBG', 'DS2_GRU_BWD_BCAST')}
+
+    def timed(which, bits, spare=0):
+        os.environ['DS2_GRU_DBG'] = str(bits)
+        durs = []
+        for _ in range(4):
+            g = gates.clone()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if which == 'fwd':
+                rc = L.ds2_gru_bidir_fwd_persistent(g.data_ptr(), ghn.data_ptr(), hout.data_ptr(), w.data_ptr(), ws.data_ptr(),
+                                                    t, bsz, hid, st)
+            else:
+                rc = L.ds2_gru_bidir_bwd_persistent_ex(g.data_ptr(), ghn.data_ptr(), hout.data_ptr(), d_out.data_ptr(),
+                                                       wt.data_ptr(), ws.data_ptr(), t, bsz, hid, spare, st)
+            e1.record()
+            torch.cuda.synchronize()
+            if rc != 0:
+                return None
+            durs.append(e0.elapsed_time(e1) * 1e3 / t)
+        ws.zero_()
+        return float(np.median(durs[1:]))
+
+    out = {}
+    try:
+        os.environ['DS2_GRU_BWD_BCAST'] = '1'          # (the top layer's 20-unit form in the same deal as the forms below)
+        for name, which, spare in (('fwd', 'fwd', 0), ('bwd_top_layer_form', 'bwd', 0), ('bwd_lower_layers_form', 'bwd', spare_below)):
+            full, skel, mat, hand = (timed(which, b, spare) for b in (0, 2 + 8192, 2048 + 8192, 4096 + 8192))
+            if None in (full, skel, mat, hand):
+                return None
+            out[name] = {'skeleton': round(skel, 3), 'handoff': round(hand - skel, 3), 'matrix': round(mat - skel, 3),
+                         'floor': round(max(hand, mat), 3), 'achieved_same_build': round(full, 3)}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    out['note'] = ('us per time step, measured in THIS run on the fault-injection build of the shipped kernels (DS2_GRU_DBG '
+                   'ablation bits: 2 skeleton only, 2048 no validation = matrix + skeleton, 4096 no MFMAs = hand-off + '
+                   'skeleton, each with 8192 = no saved-activation prefetch, whose HBM latency a full step never waits for but a '
+                   'shortened one would); hand-off and matrix both contain the hand-off loads\' own round trip; floor = max(hand-off, matrix) + skeleton, because the shipped kernels multiply a fragment as '
+                   'soon as it has landed; achieved_same_build = the unablated launch of the same library (the 20-unit '
+                   'backward form is timed in the broadcast deal here; the release library runs it in the 16-k-blocks deal)')
+    return out
+
+
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak; 6 bf16 products per fp32-equivalent one
 
 
@@ -729,6 +804,8 @@ def main():
     t_mean = int(round(np.mean([out_steps_of(b) / len(b[0]) for b in mine])))
     note('inference leg done')
     roof = gru_pass_roofline(model, bsz, t_mean)
+    from codes.model import _BWD_SPARE_CUS
+    floor = recurrence_floor(bsz, t_mean, model._rnn_hidden_size, dev, _BWD_SPARE_CUS)
     gemm_roof = gemm_roofline(model, t_mean * bsz)
     note('roofline legs done')
     mean_bin = min(range(len(mine)), key=lambda i: abs(out_steps_of(mine[i]) / len(mine[i][0]) - t_mean))
@@ -744,11 +821,11 @@ def main():
     # HBM-side bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of the same shape whose
     # summary is committed under profiles/ (PMC collection cannot run inside this process); the file is named below
     traffic, traffic_src = None, None
-    for name in ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json'):
+    for name in ('r05_traffic.json',):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
-                traffic = rec['gru_bwd_persistent4_kernel']['traffic_bytes_per_launch']
+                traffic = rec['backward_recurrence_launch']['traffic_bytes_per_launch']
                 traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gru_step_timing.py, ' \
                               'not measured in this run)' % name
                 break
@@ -805,20 +882,13 @@ def main():
                                    'of the CUs it occupies, and the gate / reduction skeleton (DESIGN.md section 6).  achieved / '
                                    'peak / frac price the launch against the fp32-input MFMA roof (the contract\'s yardstick); '
                                    'floor_us_per_step is what the latency model allows',
-                     'kernel': 'gru_bwd_persistent4_kernel (one launch = all T=%d steps of a BiGRU layer, both '
-                               'directions, B=%d)' % (t_mean, bsz),
+                     'kernel': 'the backward recurrence launch: gru_bwd_persistent5_kernel<5, 7> under the layers below the top '
+                               'one, gru_bwd_persistent4_kernel<5, 5, 2, 3> under the top layer (one launch = all T=%d steps of a '
+                               'BiGRU layer, both directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                      'avg_launch_us': round(dur * 1e6, 1), 'us_per_time_step': round(dur * 1e6 / t_mean, 3),
-                     'floor_us_per_step': {
-                         'handoff_all_to_all': 1.3, 'matrix_phase_bwd_top_layer_form': 0.83, 'matrix_phase_bwd_lower_layers_form': 1.17,
-                         'matrix_phase_fwd': 0.73, 'sum_bwd_top_layer_form': 2.13, 'sum_bwd_lower_layers_form': 2.47, 'sum_fwd': 2.03,
-                         'note': 'measured floors at B = 10, H = 800: a two-operation (store, load) all-to-all hand-off across '
-                                 'XCDs costs 1.3-1.5 us (tools/spec_handoff_probe.hip); the matrix phase is 200 / 280 (bwd: 20 '
-                                 'units per CU under the top layer, 28 under the others, where the launch leaves 82 CUs to the '
-                                 'weight-gradient GEMMs) resp. 200 (fwd, 20 units, k dealt evenly) v_mfma_f32_4x4x1 per SIMD at '
-                                 '8.8-10 cycles / 2.4 GHz; the gate / reduction skeleton (0.4 us on the chain today) has no '
-                                 'hardware floor'},
+                     'floor_us_per_step': floor,
                      'flop_per_launch': flop,
                      'launch_forms_us': {
                          'top layer (nothing queued beside it: the widest grid)': round(roof['bwd_top'][1] * 1e6, 1),

@@ -41,6 +41,10 @@ const char* ds2_last_error(void);
  * against another revision mis-passes arguments.  ds2hip/lib.py refuses to load a library whose number differs. */
 #define DS2_ABI_VERSION 401
 int ds2_version(void);
+/* A digest of the sources the loaded binary was built from (csrc/build.py: source_id(); "unstamped" for a build made without
+ * build.py).  The Python binding recomputes it from the tree beside it and refuses a binary built from other sources, so a
+ * stale .so cannot be tested or benchmarked by accident (DS2_SKIP_BUILD_CHECK=1 overrides, for binary-only installs). */
+const char* ds2_build_id(void);
 
 /* ------------------------------------------------------------------ frontend
  * Replaces ToSpectrogram.__call__ (librosa branch), codes/transforms.py:94-119, run per

@@ -47,6 +47,31 @@ def test_library_exports_every_declared_symbol():
     assert lib.query('ds2_bn_ws_bytes', 32) > 0
 
 
+def test_build_id_ties_the_binary_to_the_tree(tmp_path, monkeypatch):
+    """``ds2_build_id()`` = csrc/build.py: source_id(), a digest of every source the library is built from; the binding
+    recomputes it when it loads the library and refuses a binary built from other sources (a .so is cached by mtime and
+    travels to the GPU box beside the sources -- nothing else says it is the tree's)."""
+    import importlib.util
+    from ds2hip import lib
+    spec = importlib.util.spec_from_file_location('ds2_build_t', os.path.join(ROOT, 'aes-lac-2018_amd', 'csrc', 'build.py'))
+    build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build)
+    have = lib.load().ds2_build_id().decode()
+    assert have == build.source_id() and len(have) == 32
+    for variant in ('libds2hip_faultinject.so',):                       # built by the same build(): the same stamp
+        handle = ctypes.CDLL(os.path.join(os.path.dirname(lib.LIB_PATH), variant))
+        handle.ds2_build_id.restype = ctypes.c_char_p
+        assert handle.ds2_build_id().decode() == have
+    # a digest of other sources is refused
+    monkeypatch.setattr(build, 'source_id', lambda: '0' * 32)
+    monkeypatch.setattr(importlib.util, 'module_from_spec', lambda spec: build)
+    monkeypatch.setattr(type(spec.loader), 'exec_module', lambda self, mod: None)
+    with pytest.raises(RuntimeError, match='built from other sources'):
+        lib._check_build_id(lib.load())
+    monkeypatch.setenv('DS2_SKIP_BUILD_CHECK', '1')
+    lib._check_build_id(lib.load())
+
+
 def test_missing_device_tensor_fails_loudly():
     from ds2hip import ops
     with pytest.raises(RuntimeError):
