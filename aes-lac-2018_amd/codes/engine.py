@@ -102,6 +102,7 @@ class Trainer(object):
         self._fused = self._fused_ok()
         if self._fused:
             self._bind_momentum()
+        self._bound_flat = model._flat_p           # the spans, the momentum views and the optimizer state are tied to THIS buffer
 
     def reserve(self, nbytes):
         """Grow the caching allocator's pool by one block of ``nbytes`` now, so that the first minibatch of every new
@@ -179,6 +180,12 @@ class Trainer(object):
             bns = self._bn_modules = [m for m in model.modules() if hasattr(m, 'num_batches_tracked')]
         if not model.training or not all(m.training for m in bns):
             model.train()
+        if model._flat_p is not self._bound_flat:
+            # (a sub-module or parameter was replaced after this Trainer was built -- fine-tuning surgery belongs BEFORE the
+            # optimizer and the trainer are created, as train.py does it: the flat spans of the fused update, the momentum
+            # views and the optimizer's parameter list all point at the old buffer)
+            raise RuntimeError('the model\'s parameters were re-packed after this Trainer was built (a swapped sub-module or '
+                               're-assigned parameter): create the optimizer and the Trainer after the last change to the model')
         t0 = time.time()
         inputs, targets, input_percentages, target_sizes = batch
         if self.frontend is not None and not isinstance(inputs, torch.Tensor):   # list of clips or a RawAudioBatch

@@ -27,6 +27,8 @@ import torch.nn as nn
 
 from ds2hip import ops
 
+from .utils.dist_utils import top_layer_spare_cus
+
 
 # ------------------------------------------------------------------------------------ parameter holders
 class _Conv2dParams(nn.Module):
@@ -495,7 +497,7 @@ class DeepSpeech(nn.Module):
             # (data-parallel runs: the head's all-reduce is in flight beside the top layer's launch, and RCCL's channel
             # kernels -- up to NCCL_MAX_NCHANNELS = 32 workgroups that may be WAITING for a peer -- must not share the chip with
             # a grid that needs 240 of its 256 CUs resident at once: room for them there too)
-            top_spare = 0 if grad_ready is None else 40
+            top_spare = 0 if grad_ready is None else top_layer_spare_cus()   # (a collective beside it: one CU per RCCL channel + 8)
             spare = (top_spare if li == nl - 1 else _BWD_SPARE_CUS) if side is not None else top_spare
             ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid, spare_cus=spare)   # gates -> d(gi), ghn -> d(gh_n)
             self._tick('BiGRU recurrence backward (weight-gradient GEMMs beside it)')

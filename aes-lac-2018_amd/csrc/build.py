@@ -89,7 +89,7 @@ def build_gemm_variant(name, flags, src_name='gemm.hip'):
     src = os.path.join(HERE, src_name)
     obj = os.path.join(OBJ, '%s_%s.o' % (src_name[:-4], name))
     out = os.path.join(PKG, 'ds2hip', 'libds2hip_%s.so' % name)
-    r = subprocess.run([HIPCC] + FLAGS + list(flags) + ['-c', src, '-o', obj], capture_output=True, text=True)
+    r = subprocess.run([HIPCC] + FLAGS + ['-DDS2_ABLATION_BUILD=1'] + list(flags) + ['-c', src, '-o', obj], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed:\n%s\n%s' % (r.stdout, r.stderr))
     objs = [os.path.join(OBJ, f[:-4] + '.o') for f in sorted(os.listdir(HERE)) if f.endswith('.hip')]

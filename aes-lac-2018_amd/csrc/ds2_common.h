@@ -55,3 +55,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// Timing-only ablation switches (DS2_GEMM_ABL: gemm.hip, split_bf16.h; DS2_WGRAD_ABL: conv.hip) switch parts of a kernel's
+// loop off: the results are WRONG.  They exist for tools/gemm_ablate.py's variant libraries (csrc/build.py:
+// build_gemm_variant passes -DDS2_ABLATION_BUILD=1 beside them); a release build that defines one by accident does not compile.
+#if ((defined(DS2_GEMM_ABL) && DS2_GEMM_ABL) || (defined(DS2_WGRAD_ABL) && DS2_WGRAD_ABL)) && !defined(DS2_ABLATION_BUILD)
+#error "DS2_GEMM_ABL / DS2_WGRAD_ABL produce wrong results: define DS2_ABLATION_BUILD=1 with them (ablation variant libraries only)"
+#endif
+

@@ -37,9 +37,11 @@ def spectrogram(wav, wav_offsets, t_max, normalize=True, eps=1e-9):
     if wav_offsets.is_cuda:
         lib.call('ds2_spectrogram_fwd', wav, wav_offsets, bsz, t_max, int(normalize), float(eps), out, ws)
     else:
-        slot, staged = _pinned.stage(wav_offsets)
-        lib.call('ds2_spectrogram_fwd', wav, staged.data_ptr(), bsz, t_max, int(normalize), float(eps), out, ws)
-        _pinned.staged_done(wav_offsets.dtype, slot)
+        slot, staged = _staged.stage(wav_offsets)
+        try:
+            lib.call('ds2_spectrogram_fwd', wav, staged.data_ptr(), bsz, t_max, int(normalize), float(eps), out, ws)
+        finally:
+            _staged.staged_done(wav_offsets.dtype, slot)
     return out
 
 
@@ -135,63 +137,81 @@ def decode_augment(pcm, offsets, tempos=None, gains_db=None, sample_rate=16000, 
 class _PinnedRing(object):
     """A few reusable page-locked staging buffers per dtype: ``tensor.pin_memory()`` allocates page-locked memory
     on every call (~0.1-0.3 ms of host time each, with the GPU idle at the start of a step).  A slot is reused only
-    after the copy that last read it has completed (event per slot)."""
+    after the copy that last read it has completed (event per slot); a slot handed out by ``stage`` is BUSY until
+    ``staged_done`` and is skipped meanwhile (the ring grows if every slot is busy).  One lock per ring: frontends run on the
+    prefetch thread of a loader as well as on the main thread."""
 
     def __init__(self, slots=4):
-        self.slots, self.ring, self.next = slots, {}, {}
+        import threading
+        self.slots, self.ring, self.next, self.lock = slots, {}, {}, threading.Lock()
 
-    def _slot(self, dtype, n):
+    def _slot(self, dtype, n, busy=False):
+        """(under the lock) index and buffer of the next slot that is not busy; marks it busy if asked."""
         ring = self.ring.setdefault(dtype, [None] * self.slots)
-        i = self.next.get(dtype, 0)
-        self.next[dtype] = (i + 1) % self.slots
-        buf, ev = ring[i] if ring[i] is not None else (None, None)
+        start = self.next.get(dtype, 0)
+        i = None
+        for d in range(len(ring)):
+            j = (start + d) % len(ring)
+            if ring[j] is None or not ring[j][2]:
+                i = j
+                break
+        if i is None:                             # every slot is between stage() and staged_done(): one more
+            ring.append(None)
+            i = len(ring) - 1
+        self.next[dtype] = (i + 1) % len(ring)
+        buf, ev = (ring[i][0], ring[i][1]) if ring[i] is not None else (None, None)
         if ev is not None:
             ev.synchronize()
         if buf is None or buf.numel() < n:
             buf = torch.empty(max(64, 2 * n), dtype=dtype).pin_memory()
-        ring[i] = (buf, None)
+        ring[i] = (buf, None, busy)
         return i, buf
 
     def upload(self, host_tensor, device):
         """1-D CPU tensor -> device tensor through a pinned slot, asynchronously on the current stream."""
         n = host_tensor.numel()
-        i, buf = self._slot(host_tensor.dtype, n)
-        buf[:n].copy_(host_tensor.reshape(-1))
-        out = torch.empty(n, dtype=host_tensor.dtype, device=device)
-        out.copy_(buf[:n], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.ring[host_tensor.dtype][i] = (buf, ev)
+        with self.lock:
+            i, buf = self._slot(host_tensor.dtype, n)
+            buf[:n].copy_(host_tensor.reshape(-1))
+            out = torch.empty(n, dtype=host_tensor.dtype, device=device)
+            out.copy_(buf[:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.ring[host_tensor.dtype][i] = (buf, ev, False)
         return out
 
     def stage(self, host_tensor):
         """1-D CPU tensor -> a page-locked copy the DEVICE reads in place (its address is valid there): for a few dozen bytes a
         kernel reads once, the host-to-device copy costs more than the reads over the bus -- and, issued into an idle queue at
         the top of a step, ~50-80 us before it even starts (kernel trace).  Call ``staged_done(i)`` behind the last launch that
-        reads it: the slot is reused only after that launch has completed."""
+        reads it: until then the slot is busy, afterwards it is reused only once that launch has completed."""
         n = host_tensor.numel()
-        i, buf = self._slot(host_tensor.dtype, n)
-        view = buf[:n]
-        view.copy_(host_tensor.reshape(-1))
+        with self.lock:
+            i, buf = self._slot(host_tensor.dtype, n, busy=True)
+            view = buf[:n]
+            view.copy_(host_tensor.reshape(-1))
         return i, view
 
     def staged_done(self, dtype, i):
         ev = torch.cuda.Event()
         ev.record()
-        self.ring[dtype][i] = (self.ring[dtype][i][0], ev)
+        with self.lock:
+            self.ring[dtype][i] = (self.ring[dtype][i][0], ev, False)
 
     def download(self, dev_tensor):
         """1-D device tensor -> pinned host view; valid once the returned event has completed."""
         n = dev_tensor.numel()
-        i, buf = self._slot(dev_tensor.dtype, n)
-        buf[:n].copy_(dev_tensor.reshape(-1), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.ring[dev_tensor.dtype][i] = (buf, ev)
+        with self.lock:
+            i, buf = self._slot(dev_tensor.dtype, n)
+            buf[:n].copy_(dev_tensor.reshape(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.ring[dev_tensor.dtype][i] = (buf, ev, False)
         return buf[:n], ev
 
 
 _pinned = _PinnedRing()
+_staged = _PinnedRing()          # device-read-in-place staging has its own ring: uploads never wait behind a staged slot
 
 
 def upload_small(host_tensor, device):

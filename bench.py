@@ -617,7 +617,9 @@ def main():
     if world > 1 or os.environ.get('DS2_BENCH_FORCE_DIST') == '1':
         # hardware-queue count and RCCL channel cap: ONE function shared with train.py (codes/utils/dist_utils.py); read by
         # the runtime / RCCL when they start, so applied before the first torch.cuda call
-        data_parallel_env()
+        dp_env = data_parallel_env()
+    else:
+        dp_env = None
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X: the product path has no CPU fallback')
     # a benchmark must never report the launch-per-step fall-back's rate as the product's: a persistent recurrence launch
@@ -907,6 +909,7 @@ def main():
     if cfg3 is not None:
         result['config']['config3'] = cfg3
     if ddp is not None:
+        ddp['environment'] = dp_env          # queue / channel settings and the CPU placement applied (codes/utils/dist_utils.py)
         result['config']['data_parallel'] = ddp
     if world == 1 and not args.no_extras:
         # the other single-GPU BASELINE shapes on the same model, a few steps each

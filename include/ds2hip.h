@@ -218,7 +218,9 @@ int ds2_transpose2d(const float* in, int rows, int cols, float* out, void* strea
  * when it allocates it: a launch that completes leaves its counters zero for the next one (the last
  * workgroup to leave resets them), so no memset runs between launches.  Every spin is bounded (5 s):
  * on a timeout the 32-bit word at byte offset ds2_gru_sync_error_offset() of sync_ws is set to 1 and
- * the launch ends (results are then invalid).  The word is STICKY -- later launches never clear it --
+ * the launch ends.  EVERY output of a launch that sets the word -- G, ghn, hout and the exchange ring -- is UNDEFINED: the
+ * step in which the time-out happened still publishes a payload computed from the missing fragment and stores its
+ * activations before the workgroups return.  The word is STICKY -- later launches never clear it --
  * so one check after synchronising at the end of a step covers every launch of the step; after a
  * reported timeout the caller zeroes the whole workspace before using it again.
  * All workgroups of a launch must be resident at once: ds2_gru_persistent_supported(B, H) answers for

@@ -3,8 +3,9 @@
 
     python tests/ddp_worker.py RANK WORLD PORT OUT.npz [cpu-store]
 
-Both ranks share cuda:0 (the box has one GPU); the process group is ``gloo`` on device tensors, and the parent
-sets DS2_GRU_MODE=step so two persistent recurrence kernels never compete for the same CUs.  Rank r != 0 starts from
+Both ranks share cuda:0 (the box has one GPU); the process group is ``gloo`` on device tensors.  The parent sets
+DS2_GRU_MODE: ``step`` (the launch-per-step kernels) or ``persistent`` (the product's kernels: at this model's width a
+launch is 8-24 workgroups, so both ranks' launches fit on the one GPU together).  Rank r != 0 starts from
 DIFFERENT weights: the trainer's construction-time broadcast must overwrite them (DDP semantics).
 """
 import os

@@ -33,6 +33,7 @@ path, loads the portable weights-from-seed recipe (oracle/model.py
                  the same model with every weight matrix drawn 3x wider (``seeded_state_dict(scale=3.0)``): confident
                  outputs, a recurrence that is much less contractive, T_in = 801.
   ref_traj_b10.npz
+  ref_traj_frozen_b10.npz
                  FIVE optimisation steps of the reference model as ``codes/engine.py:45-94`` runs them (loss / B,
                  ``clip_grad_norm_(400)``, SGD lr 3e-4 momentum 0.9 Nesterov -- scripts/librispeech-from_scratch.json) on
                  two alternating B=10 minibatches: per-step loss and gradient norm, the final BatchNorm buffers, strided
@@ -92,9 +93,9 @@ def label_lengths_for(lengths, per_frame=0.09):
 
 
 def run_case(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, full_grads, tstride=1, finetune43=False,
-             f64_truth=False, weight_scale=None, trajectory=0, lnoise=False):
+             f64_truth=False, weight_scale=None, trajectory=0, lnoise=False, frozen_conv=False):
     if trajectory:
-        return run_trajectory(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, trajectory)
+        return run_trajectory(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, trajectory, frozen_conv)
     torch.manual_seed(0)
     model = ref.DeepSpeech(**model_kwargs)
     sd = seeded_state_dict(model, seed=1234, scale=weight_scale)
@@ -209,12 +210,21 @@ TRAJ_OPT = dict(lr=3e-4, momentum=0.9, nesterov=True)      # scripts/librispeech
 TRAJ_MAX_NORM = 400.0
 
 
-def run_trajectory(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, steps):
+def run_trajectory(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, steps, frozen_conv=False):
     """``steps`` updates of the reference model exactly as codes/engine.py:45-94 does them (warp-ctc's place taken by
-    F.ctc_loss on log_softmax, reduction sum -- SURVEY 8c)."""
+    F.ctc_loss on log_softmax, reduction sum -- SURVEY 8c).  ``frozen_conv``: after ``_freeze_layers(model, ['conv'])``
+    (codes/utils/training_utils.py:57-84, restated: its module cannot be imported here): the conv block's BatchNorm modules
+    put in eval mode once, its parameters ``requires_grad = False`` -- and ``model.train()`` at the top of every step
+    (codes/engine.py:51) as below, which returns that BatchNorm to training mode."""
     torch.manual_seed(0)
     model = ref.DeepSpeech(**model_kwargs)
     model.load_state_dict(seeded_state_dict(model, seed=1234))
+    if frozen_conv:
+        for m in model.conv.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.eval()
+        for p in model.conv.parameters():
+            p.requires_grad = False
     opt = torch.optim.SGD(model.parameters(), **TRAJ_OPT)
     batches = traj_batches(bsz, t_in, lengths, label_lens)
     pct = torch.tensor([n / float(t_in) for n in lengths], dtype=torch.float32)
@@ -241,8 +251,8 @@ def run_trajectory(ref, name, model_kwargs, bsz, t_in, lengths, label_lens, step
         stride = max(1, flat.shape[0] // 1024)
         out['wsample_' + k] = flat[::stride][:1024].copy()
         out['wnorm_' + k] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
-        mom = opt.state[p]['momentum_buffer'].numpy().reshape(-1)
-        out['msample_' + k] = mom[::stride][:1024].copy()
+        mom = opt.state[p]['momentum_buffer'].numpy().reshape(-1) if 'momentum_buffer' in opt.state[p] else np.zeros_like(flat)
+        out['msample_' + k] = mom[::stride][:1024].copy()                 # (a frozen parameter has no buffer: zeros)
     for k, v in model.state_dict().items():
         if 'running' in k:
             out['buf_' + k] = v.numpy().copy()
@@ -286,6 +296,11 @@ def cases():
     lens = ragged_lengths(510, 10, 301)
     yield 'ref_traj_b10.npz', dict(model_kwargs=dict(), bsz=10, t_in=301, lengths=lens,
                                    label_lens=label_lengths_for(lens), full_grads=False, trajectory=5)
+    # round 5: the same five steps with the conv block frozen (scripts/pt_BR-finetune-freeze.json): the conv block's hard clip
+    # is the model's only non-smooth function and its gradient mask only reaches the conv filters, so with those frozen the
+    # trajectories of two fp32 implementations stay within round-off of each other -- the tight form of the trajectory test
+    yield 'ref_traj_frozen_b10.npz', dict(model_kwargs=dict(), bsz=10, t_in=301, lengths=lens,
+                                          label_lens=label_lengths_for(lens), full_grads=False, trajectory=5, frozen_conv=True)
 
 
 CASES = dict(cases())

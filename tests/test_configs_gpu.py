@@ -189,18 +189,31 @@ def test_config4_finetuned_pt_br_head_full_size_with_beam():
     assert all(isinstance(s[0], str) for s in wide)
 
 
-def test_five_step_trajectory_against_the_reference_model(golden_dir):
+@pytest.mark.parametrize('frozen_conv', [False, True])
+def test_five_step_trajectory_against_the_reference_model(golden_dir, frozen_conv):
     """FIVE optimisation steps of the fused trainer (CTC / B, clip 400, lr 3e-4, momentum 0.9, Nesterov -- the
     librispeech-from_scratch.json settings) against the same five steps of the REFERENCE model under torch.optim.SGD +
     clip_grad_norm_ (tests/golden/make_golden.py::run_trajectory, codes/engine.py:45-94): per-step loss and gradient
     norm, the final weights, momentum buffers, BatchNorm running statistics and eval-mode probabilities.  The clip
     engages in steps 0-2 (gradient norms 1.3e3, 2.2e3, 8.5e2 > 400) and not in steps 3-4 (2.2e2): both sides of the
-    device-computed clip coefficient; the two minibatches alternate."""
+    device-computed clip coefficient; the two minibatches alternate.
+
+    ``frozen_conv``: the same five steps after ``_freeze_layers(model, ['conv'])`` (scripts/pt_BR-finetune-freeze.json), against
+    ``ref_traj_frozen_b10.npz`` -- the TIGHT form of the test.  The conv block's hard clip is the model's only non-smooth
+    function, and its gradient mask only reaches the conv filters: with those frozen, an activation that lands on the other
+    side of the clip boundary in one of the two fp32 implementations changes nothing that is applied, and the weight move and
+    the momentum buffers are held to 5e-3 of the largest entry (5e-2 in the unfrozen form, where one flipped mask moves a
+    conv filter gradient by per cents): a 3 % error in the clip coefficient or in the Nesterov term cannot pass here.  The
+    clip engages in steps 0-1 (gradient norms 789, 1074) and not in steps 2-4 (155, 111, 170)."""
     from codes.engine import Trainer
+    from codes.utils.training_utils import _freeze_layers
     from tests.golden.make_golden import CASES, TRAJ_MAX_NORM, TRAJ_OPT, traj_batches
-    g = np.load(os.path.join(golden_dir, 'ref_traj_b10.npz'))
-    kw = CASES['ref_traj_b10.npz']
+    fixture = 'ref_traj_frozen_b10.npz' if frozen_conv else 'ref_traj_b10.npz'
+    g = np.load(os.path.join(golden_dir, fixture))
+    kw = CASES[fixture]
     model = _seeded_model()
+    if frozen_conv:
+        _freeze_layers(model, ['conv'])
     opt = torch.optim.SGD(model.parameters(), **TRAJ_OPT)
     trainer = Trainer(model, opt, device='cuda', max_norm=TRAJ_MAX_NORM)
     assert trainer._fused
@@ -214,9 +227,11 @@ def test_five_step_trajectory_against_the_reference_model(golden_dir):
         gnorms.append(trainer.last_grad_norm)
     # step 0 starts from identical weights: tight; later steps inherit the earlier steps' fp32 differences
     assert abs(losses[0] - g['losses'][0]) <= 1e-4 * g['losses'][0], (losses, g['losses'])
-    np.testing.assert_allclose(losses, g['losses'], rtol=5e-4)
-    np.testing.assert_allclose(gnorms, g['gnorms'], rtol=5e-3)
-    assert [v > TRAJ_MAX_NORM for v in gnorms] == [True, True, True, False, False]   # clipped and unclipped steps
+    np.testing.assert_allclose(losses, g['losses'], rtol=1e-4 if frozen_conv else 5e-4)
+    np.testing.assert_allclose(gnorms, g['gnorms'], rtol=1e-3 if frozen_conv else 5e-3)
+    # clipped and unclipped steps
+    assert [v > TRAJ_MAX_NORM for v in gnorms] == ([True, True, False, False, False] if frozen_conv else [True, True, True, False, False])
+    tol = 5e-3 if frozen_conv else 5e-2
     # The weights themselves barely move in five steps (lr 3e-4), so what is compared is the MOVE: final - initial weight
     # (the initial weights come from the seeded recipe on both sides) and the momentum buffer (pure accumulated gradient),
     # each against the reference's, relative to the largest entry of the reference's sample.  5 %: the trajectories are two
@@ -232,6 +247,11 @@ def test_five_step_trajectory_against_the_reference_model(golden_dir):
             bad.append((k, 'wnorm', wn, float(g['wnorm_' + k])))
         if k in ('conv.0.bias', 'conv.3.bias'):
             continue                                                    # exactly-zero gradients: round-off on both sides
+        if frozen_conv and k.startswith('conv.'):                       # frozen: bit-identical to the seeded weights, no momentum
+            assert np.array_equal(flat, init[k].numpy().reshape(-1)), k
+            buf = opt.state[p].get('momentum_buffer')
+            assert buf is None or not bool(buf.any()), k
+            continue
         w0 = init[k].numpy().reshape(-1)[::stride][:1024]
         move, move_ref = flat[::stride][:1024] - w0, g['wsample_' + k] - w0
         mom = opt.state[p]['momentum_buffer'].detach().cpu().numpy().reshape(-1)[::stride][:1024]
@@ -239,7 +259,7 @@ def test_five_step_trajectory_against_the_reference_model(golden_dir):
         e_w = float(np.abs(move - move_ref).max() / np.abs(move_ref).max())
         e_m = float(np.abs(mom - mref).max() / np.abs(mref).max())
         report.append('%s move %.2e momentum %.2e' % (k, e_w, e_m))
-        if e_w > 5e-2 or e_m > 5e-2:
+        if e_w > tol or e_m > tol:
             bad.append((k, 'move/momentum', e_w, e_m))
     print('\n'.join(report))
     assert not bad, bad

@@ -17,12 +17,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('overlap', ['1', '0'])
-def test_two_rank_step_matches_ddp_oracle(tmp_path, overlap):
+@pytest.mark.parametrize('overlap,gru_mode', [('1', 'step'), ('0', 'step'), ('1', 'persistent')])
+def test_two_rank_step_matches_ddp_oracle(tmp_path, overlap, gru_mode):
+    """``gru_mode='persistent'`` (round 5): the same two ranks with the PERSISTENT recurrence kernels -- the forms the product
+    runs (gru_fwd_persistent4_kernel / gru_bwd_persistent4_kernel, speculative hand-off) -- so that the overlapped all-reduce
+    (per-layer slices on the comm stream, gated by events of the main and the weight-gradient stream) meets persistent
+    launches of BOTH ranks on one GPU.  At the test model's width (H = 32) a launch is 8-24 workgroups: the two ranks'
+    launches are co-resident together, which two full-width ones (174-240 workgroups each) on ONE GPU could not be -- on a real
+    node every rank has its own GPU.  DS2_GRU_STRICT=1: a fall-back to the per-step kernels fails the rank."""
     from tests import ddp_common as dc
     world = 2
-    port = 29700 + (os.getpid() % 200) + (7 if overlap == '1' else 0)
-    env = dict(os.environ, DS2_GRU_MODE='step', DS2_ALLREDUCE_OVERLAP=overlap)
+    port = 29700 + (os.getpid() % 200) + (7 if overlap == '1' else 0) + (13 if gru_mode == 'persistent' else 0)
+    env = dict(os.environ, DS2_GRU_MODE=gru_mode, DS2_ALLREDUCE_OVERLAP=overlap, DS2_GRU_STRICT='1')
     outs = [str(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
 
     def run_ranks(port):

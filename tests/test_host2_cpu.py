@@ -520,3 +520,51 @@ def test_bench_bin_plan_is_the_reference_partition(world):
     assert float(win.max() / win.min()) < 1.6                           # any four consecutive steps: about the mean length
     for e in plan:
         assert np.all(np.diff(e[1]) >= 0) and 1.0 <= e[1][0] and e[1][-1] <= 15.0
+
+
+def _fake_node(tmp_path, gpu_numa=(0, 0, 0, 0, 1, 1, 1, 1), cpus_per_node=16):
+    """A sysfs tree of a two-socket node: KFD nodes 0-1 are the CPUs, 2.. the GPUs (one PCI bus each)."""
+    root = tmp_path / 'sysfs'
+    for n in range(2):
+        d = root / 'sys/class/kfd/kfd/topology/nodes' / str(n)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text('cpu_cores_count %d\nsimd_count 0\nlocation_id 0\ndomain 0\n' % cpus_per_node)
+        nd = root / ('sys/devices/system/node/node%d' % n)
+        nd.mkdir(parents=True)
+        (nd / 'cpulist').write_text('%d-%d\n' % (n * cpus_per_node, (n + 1) * cpus_per_node - 1))
+    for g, numa in enumerate(gpu_numa):
+        d = root / 'sys/class/kfd/kfd/topology/nodes' / str(2 + g)
+        d.mkdir(parents=True)
+        bus = 0x10 + 0x10 * g
+        (d / 'properties').write_text('cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n' % (bus << 8))
+        pd = root / ('sys/bus/pci/devices/0000:%02x:00.0' % bus)
+        pd.mkdir(parents=True)
+        (pd / 'numa_node').write_text('%d\n' % numa)
+    return str(root)
+
+
+def test_numa_cpu_plan_on_a_two_socket_node(tmp_path):
+    """codes/utils/dist_utils.py: every rank lands on its GPU's NUMA node, the ranks of one node get disjoint equal shares,
+    visible-device lists are honoured, and anything unknown leaves the affinity alone."""
+    from codes.utils import dist_utils as du
+    root = _fake_node(tmp_path)
+    assert du.gpu_numa_nodes(root, {}) == [0, 0, 0, 0, 1, 1, 1, 1]
+    plans = [du.numa_cpu_plan(r, 8, sysfs=root, environ={}, current=set(range(32))) for r in range(8)]
+    assert plans[0] == {0, 1, 2, 3} and plans[3] == {12, 13, 14, 15} and plans[4] == {16, 17, 18, 19} and plans[7] == {28, 29, 30, 31}
+    assert all(not (plans[a] & plans[b]) for a in range(8) for b in range(a))
+    # two ranks only: each gets half of ITS node (both GPUs are on node 0 here)
+    assert du.numa_cpu_plan(1, 2, sysfs=root, environ={}, current=set(range(32))) == set(range(8, 16))
+    # HIP_VISIBLE_DEVICES remaps local rank 0 to the fifth GPU (node 1)
+    env = {'HIP_VISIBLE_DEVICES': '4,5'}
+    assert du.gpu_numa_nodes(root, env) == [1, 1]
+    assert du.numa_cpu_plan(0, 2, sysfs=root, environ=env, current=set(range(32))) == set(range(16, 24))
+    assert du.gpu_numa_nodes(root, {'HIP_VISIBLE_DEVICES': 'GPU-abcdef'}) == []
+    # a container's mask that is already inside one node, an unknown NUMA node, no topology: hands off
+    assert du.numa_cpu_plan(0, 8, sysfs=root, environ={}, current={0, 1, 2, 3}) is None
+    assert du.numa_cpu_plan(0, 8, sysfs=_fake_node(tmp_path / 'b', gpu_numa=(-1,) * 8), environ={}, current=set(range(32))) is None
+    assert du.numa_cpu_plan(0, 8, sysfs=str(tmp_path / 'nothing'), environ={}, current=set(range(32))) is None
+    assert du.top_layer_spare_cus({}) == 40 and du.top_layer_spare_cus({'NCCL_MAX_NCHANNELS': '16'}) == 24
+    # data_parallel_env on a foreign environ never touches this process's affinity
+    before = os.sched_getaffinity(0)
+    out = du.data_parallel_env({'LOCAL_RANK': '0'})
+    assert out == {'GPU_MAX_HW_QUEUES': '3', 'NCCL_MAX_NCHANNELS': '32'} and os.sched_getaffinity(0) == before

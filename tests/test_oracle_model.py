@@ -111,3 +111,46 @@ def test_sharp_weight_model_matches_reference(golden_dir):
     """3x wider weights (confident outputs, a much less contractive recurrence), T_in = 801: the oracle is the reference here
     too -- bench.py's parity block and smoke() compare the HIP path with THIS model."""
     _oracle_case(golden_dir, 'ref_sharp_b10.npz')
+
+
+def test_frozen_conv_trajectory_matches_reference(golden_dir):
+    """Five optimisation steps with the conv block frozen (``ref_traj_frozen_b10.npz``: the reference model under
+    ``torch.optim.SGD`` + ``clip_grad_norm_``, codes/engine.py:45-94 after ``_freeze_layers(model, ['conv'])``), on the
+    oracle's stock torch modules: eval() on the frozen block's BatchNorm at set-up, ``model.train()`` at the top of every
+    step -- the reference's literal sequence, under which that BatchNorm trains (tests/test_host2_cpu.py)."""
+    from tests.golden.make_golden import CASES, TRAJ_MAX_NORM, TRAJ_OPT, traj_batches
+    g = np.load(os.path.join(golden_dir, 'ref_traj_frozen_b10.npz'))
+    kw = CASES['ref_traj_frozen_b10.npz']
+    model = OracleDeepSpeech()
+    model.load_state_dict(seeded_state_dict(model, 1234))
+    for m in model.conv.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in model.conv.parameters():
+        p.requires_grad = False
+    opt = torch.optim.SGD(model.parameters(), **TRAJ_OPT)
+    batches = traj_batches(kw['bsz'], kw['t_in'], kw['lengths'], kw['label_lens'])
+    pct = torch.from_numpy(g['pct'])
+    losses, gnorms = [], []
+    for i in range(kw['trajectory']):
+        x, labels = batches[i % 2]
+        model.train()
+        logits = model(torch.from_numpy(x))
+        out_sizes = (pct * logits.shape[1]).int()
+        loss = F.ctc_loss(logits.transpose(0, 1).log_softmax(-1), torch.from_numpy(labels).long(), out_sizes.long(),
+                          torch.tensor(kw['label_lens'], dtype=torch.long), blank=0, reduction='sum') / kw['bsz']
+        opt.zero_grad()
+        loss.backward()
+        gnorms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), TRAJ_MAX_NORM)))
+        opt.step()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g['losses'], rtol=1e-5)
+    np.testing.assert_allclose(gnorms, g['gnorms'], rtol=1e-4)
+    for k, p in model.named_parameters():
+        flat = p.detach().numpy().reshape(-1)
+        stride = max(1, flat.shape[0] // 1024)
+        np.testing.assert_allclose(flat[::stride][:1024], g['wsample_' + k], rtol=1e-4, atol=1e-7, err_msg=k)
+    assert int(model.conv[1].num_batches_tracked) == 5
+    for k, v in model.state_dict().items():
+        if 'running' in k:
+            np.testing.assert_allclose(v.numpy(), g['buf_' + k], rtol=1e-4, atol=1e-6, err_msg=k)

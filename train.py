@@ -107,7 +107,7 @@ def main(argv=None):
     if args.distributed:
         # BEFORE the first torch.cuda call (is_available() already initialises the HIP runtime, which reads its flags
         # once): hardware-queue count and RCCL channel cap -- codes/utils/dist_utils.py, shared with bench.py
-        data_parallel_env()
+        dp_env = data_parallel_env()
     if not torch.cuda.is_available():
         raise RuntimeError('Training script requires GPU. :(')
     torch.manual_seed(42)
@@ -126,6 +126,8 @@ def main(argv=None):
                         handlers=[logging.StreamHandler(),
                                   logging.FileHandler(os.path.join(args.save_folder, args.config.model.name + '.log'))])
 
+    if args.distributed:
+        LOG.info('data-parallel environment: {}'.format(dp_env))
     device = torch.device('cuda' if args.local else 'cuda:{}'.format(args.local_rank))
     main_proc = True
     if args.distributed:
