@@ -315,9 +315,12 @@ class DeepSpeech(nn.Module):
         # the all-training case exists.
         # (plain instance-dict lookups: a missing attribute on an nn.Module costs a failed walk through its parameter /
         # buffer / sub-module tables and an exception -- ~3 us each, ~30 of them here, at the top of a step with the GPU idle)
-        c1_train = training and c[1].training
-        c4_train = training and c[4].training
-        if training:
+        # (a BatchNorm is "held" when it is in eval mode inside a model that is in training mode; ``training`` itself -- the
+        # caller's choice of batch or running statistics for the pass -- is independent of the flags, as before)
+        model_training = self.training
+        c1_train = training and not (model_training and not c[1].training)
+        c4_train = training and not (model_training and not c[4].training)
+        if training and model_training:
             mods = self.__dict__.get('_bn_walk')
             if mods is None:                               # the module tree is static (_ensure_flat drops this on a swap)
                 mods = self.__dict__['_bn_walk'] = [m for m in list(self.rnns.modules()) + list(self.fc.modules())

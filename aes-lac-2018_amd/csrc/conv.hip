@@ -147,115 +147,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
     }
 }
 
-// ---------------------------------------------------------------------------- conv2 forward, filter through LDS
-// In the direct kernel every wave re-reads the whole re-laid-out filter (946 KB) from L1/L2 for its one 32 x 32 NT tile:
-// 2730 tiles at B = 10 pull 2.6 GB through the L2s in half a millisecond -- that, not the MFMAs, bounds it.  Here the
-// EIGHT waves of a workgroup (eight consecutive (b, t-tile, d) tiles) share the filter slice of one input channel
-// (21 x 12 x 32 floats = 32 KB) through LDS, double-buffered: 8x less filter traffic.  A operand = conflict-free
-// ds_read_b32 (lanes = consecutive output channels); B operands stay per-wave global loads (their windows overlap in L1).
-template <int NT>
-__global__ __launch_bounds__(512) void conv2_fwd_wlds_kernel(const float* __restrict__ in, const float* __restrict__ wt,
-                                                             const float* __restrict__ bias, int B, int FIN, int TIN,
-                                                             int FOUT, int TOUT, int ttiles, float* __restrict__ out) {
-    constexpr int CIN = 32, KF = 21, SF = 2;
-    constexpr int SLICE = KF * KTP * 32;                 // floats of one input channel's filter slice
-    constexpr int NLD = SLICE / 4 / 512 + 1;             // float4 per thread (the last one partial)
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [2][SLICE]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 31, lh = lane >> 5;
-    const long ntiles = (long)B * ttiles * FOUT;
-    const long tile = (long)blockIdx.x * 8 + wave;
-    const bool tile_ok = tile < ntiles;
-    const long tl = tile_ok ? tile : 0;
-    const int d = (int)(tl % FOUT);
-    const int tt = (int)((tl / FOUT) % ttiles);
-    const int b = (int)(tl / ((long)FOUT * ttiles));
-    const int t0 = tt * 32 * NT;
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    int tbase[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) tbase[i] = t0 + 32 * i + lr + lh;
-
-    f32x4 stage[NLD];
-    auto load_slice = [&](int ci) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(wt + (size_t)ci * SLICE);
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = tid + 512 * j;
-            if (e < SLICE / 4) stage[j] = src[e];
-        }
-    };
-    auto store_slice = [&](int buf) {
-        f32x4* dst = reinterpret_cast<f32x4*>(wl + buf * SLICE);
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = tid + 512 * j;
-            if (e < SLICE / 4) dst[e] = stage[j];
-        }
-    };
-    load_slice(0);
-    store_slice(0);
-    __syncthreads();
-
-    const float* inb = in + ((size_t)b * CIN * FIN + (size_t)SF * d) * TIN;
-    for (int ci = 0; ci < CIN; ++ci) {
-        const int cur = ci & 1;
-        if (ci + 1 < CIN) load_slice(ci + 1);
-        if (tile_ok) {
-            const float* wa = wl + cur * SLICE + lh * 32 + lr;
-            float v_nxt[NT][KTP / 2];
-            auto fetch = [&](int kf) {
-                const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(inb + ((size_t)ci * FIN + kf) * TIN), 0, TIN * 4, 0x00020000);
-#pragma unroll
-                for (int kp = 0; kp < KTP / 2; ++kp)
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-                        v_nxt[i][kp] = __builtin_bit_cast(
-                            float, __builtin_amdgcn_raw_buffer_load_b32(row, (tbase[i] + 2 * kp) * 4, 0, 0));
-            };
-            fetch(0);
-#pragma unroll 3
-            for (int kf = 0; kf < KF; ++kf) {
-                float v_cur[NT][KTP / 2];
-#pragma unroll
-                for (int kp = 0; kp < KTP / 2; ++kp)
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) v_cur[i][kp] = v_nxt[i][kp];
-                if (kf + 1 < KF) fetch(kf + 1);
-                const float* wk = wa + kf * (KTP * 32);
-#pragma unroll
-                for (int kp = 0; kp < KTP / 2; ++kp) {
-                    const float a = wk[kp * 64];
-#pragma unroll
-                    for (int i = 0; i < NT; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v_cur[i][kp], acc[i], 0, 0, 0);
-                }
-            }
-        }
-        if (ci + 1 < CIN) store_slice(cur ^ 1);
-        __syncthreads();
-    }
-    if (!tile_ok) return;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int t = t0 + 32 * i + lr;
-        if (t >= TOUT) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            out[(((size_t)b * 32 + co) * FOUT + d) * TOUT + t] = acc[i][r] + bias[co];
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------- conv2 dgrad
 // d_in (B,32,FIN,T1) from d_out (B,32,FOUT,T); kernel (32,32,KF,11), stride (2,1), no padding
 template <int KF, int NT, int KS>
@@ -802,27 +693,8 @@ extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, con
     } while (0)
     if (which == 1 && nt == 2) DS2_CONV_FWD_GO(1, 41, 2, 2, 10, 2);
     else if (which == 1) DS2_CONV_FWD_GO(1, 41, 2, 2, 10, 1);
-    // filter-through-LDS form from 512 eight-tile workgroups up (two rounds of the chip; measured B = 32: 1.54 -> 1.35 ms,
-    // 92 -> 103 TFLOP/s; at B = 10 its 184-342 workgroups leave CUs idle and it ties with the direct kernel);
-    // DS2_CONV_WLDS = 0 / 1 forces one (A/B timing, tests)
-    else if (getenv("DS2_CONV_WLDS") ? getenv("DS2_CONV_WLDS")[0] == '1' : (ntiles + 7) / 8 >= 512) {
-        const size_t lds = (size_t)2 * 21 * KTP * 32 * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            DS2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_fwd_wlds_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            DS2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_fwd_wlds_kernel<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        dim3 grid2((unsigned)((ntiles + 7) / 8));
-        if (nt == 2)
-            hipLaunchKernelGGL((conv2_fwd_wlds_kernel<2>), grid2, dim3(512), lds, st, in, wt_ws, bias, B, g.fin, tin, g.fout,
-                               tout, ttiles, out);
-        else
-            hipLaunchKernelGGL((conv2_fwd_wlds_kernel<1>), grid2, dim3(512), lds, st, in, wt_ws, bias, B, g.fin, tin, g.fout,
-                               tout, ttiles, out);
-    }
+    // (a filter-through-LDS form of the direct kernel -- eight waves sharing an input channel's filter slice -- was 12 % faster
+    // from B = 32 up, round 2; the gather-GEMM on the bf16 pipe, the default since round 3, beats both: removed in round 5)
     else if (nt == 2) DS2_CONV_FWD_GO(32, 21, 2, 1, 0, 2);
     else DS2_CONV_FWD_GO(32, 21, 2, 1, 0, 1);
 #undef DS2_CONV_FWD_GO

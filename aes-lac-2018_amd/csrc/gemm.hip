@@ -430,212 +430,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_v2_kernel(int M, int N, int K
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// v3: 256 x 128 tile (4 waves as 2 x 2, each 128 x 64 = 4 x 2 MFMA tiles), three LDS slab buffers, scalar-offset loads.
-// Ablations of the 128 x 128 loop (tools/gemm_ablate.py: no LDS stores / no global loads / no LDS reads each give back
-// 10-17 %, the bare MFMA + barrier loop runs at 138-151 TFLOP/s) show the per-slab work AROUND the MFMAs is what costs:
-// a 128 x 64 wave tile issues 8 MFMAs per 6 operand reads instead of 4 per 4, and one slab's loads, LDS stores and
-// barrier are spread over 64 MFMAs instead of 32.  Work decomposition (data-parallel rounds + stream-K runs) as in v2.
-// Requires the vector fast path (16-byte chunks never straddle a tile edge); a slab that crosses K falls back to
-// checked scalar loads.
-// ----------------------------------------------------------------------------------------------------------
-template <int ROWS, bool KCONTIG>
-__device__ __forceinline__ void big_voffsets(int ld, int x0, int xmax, int tid, int (&voff)[ROWS / 64]) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-        if (KCONTIG) {
-            const int x = x0 + (tid >> 2) + 64 * i;
-            voff[i] = x < xmax ? (x * ld + (tid & 3) * 4) * 4 : OOB;
-        } else {
-            constexpr int LPR = ROWS / 4;                       // lanes per k row
-            const int x = x0 + (tid % LPR) * 4;
-            voff[i] = x < xmax ? ((tid / LPR + (256 / LPR) * i) * ld + x) * 4 : OOB;
-        }
-    }
-}
-template <int ROWS, bool KCONTIG>
-__device__ __forceinline__ void big_load(__amdgpu_buffer_rsrc_t rs, const int (&voff)[ROWS / 64], int ld, int x0, int xmax,
-                                         int k0, int kmax, int tid, bool fast, f32x4 (&r)[ROWS / 64]) {
-    if (fast) {
-        const int soff = KCONTIG ? k0 * 4 : k0 * ld * 4;
-#pragma unroll
-        for (int i = 0; i < ROWS / 64; ++i)
-            r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], soff, 0));
-    } else {                                                    // the slab that crosses kmax: element-wise, checked
-#pragma unroll
-        for (int i = 0; i < ROWS / 64; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                int x, k;
-                if (KCONTIG) {
-                    x = x0 + (tid >> 2) + 64 * i;
-                    k = k0 + (tid & 3) * 4 + c;
-                    r[i][c] = bload1(rs, (x < xmax && k < kmax) ? (x * ld + k) * 4 : OOB);
-                } else {
-                    constexpr int LPR = ROWS / 4;
-                    x = x0 + (tid % LPR) * 4 + c;
-                    k = k0 + tid / LPR + (256 / LPR) * i;
-                    r[i][c] = bload1(rs, (x < xmax && k < kmax) ? (k * ld + x) * 4 : OOB);
-                }
-            }
-    }
-}
-template <int ROWS, bool KCONTIG>
-__device__ __forceinline__ void big_store(float* __restrict__ lds, int tid, const f32x4 (&r)[ROWS / 64]) {
-    constexpr int PITCH = ROWS + 4;
-#pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-        if (KCONTIG) {
-            const int x = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) lds[(kq + c) * PITCH + x] = r[i][c];
-        } else {
-            constexpr int LPR = ROWS / 4;
-            *reinterpret_cast<f32x4*>(&lds[(tid / LPR + (256 / LPR) * i) * PITCH + (tid % LPR) * 4]) = r[i];
-        }
-    }
-}
-
-template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256, 2) void gemm_f32_v3_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                             const float* __restrict__ B, int ldb,
-                                                             float* __restrict__ C, int ldc, int tiles_n, int dp_tiles,
-                                                             int sk_units, int sk_total, unsigned int a_bytes,
-                                                             unsigned int b_bytes) {
-    constexpr int TM = 256, TN = 128, PA = TM + 4, PB = TN + 4;
-    extern __shared__ __attribute__((aligned(16))) float lds3[];           // [3][BK * (PA + PB)]
-    constexpr int BUF = BK * (PA + PB);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int nslab_all = (K + BK - 1) / BK;
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, b_bytes, 0x00020000);
-    int u0 = 0, u1 = 0;
-    const bool is_dp = (int)blockIdx.x < dp_tiles;
-    if (!is_dp) {
-        u0 = ((int)blockIdx.x - dp_tiles) * sk_units;
-        u1 = min(u0 + sk_units, sk_total);
-    }
-#pragma unroll 1
-    for (int piece = 0; piece < 2; ++piece) {
-        int tile, s_beg, s_end;
-        if (is_dp) {
-            if (piece == 1) break;
-            const int nwg = dp_tiles, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-            const int qd = nwg >> 3, rm = nwg & 7;
-            tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
-            s_beg = 0;
-            s_end = nslab_all;
-        } else {
-            if (u0 >= u1) break;
-            tile = dp_tiles + u0 / nslab_all;
-            s_beg = u0 % nslab_all;
-            s_end = min(nslab_all, s_beg + (u1 - u0));
-            u0 += s_end - s_beg;
-        }
-        const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
-        const int nslab = s_end - s_beg;
-        const int kbeg = s_beg * BK, kend = min(K, s_end * BK);
-
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        f32x4 ra[4], rb[2];
-        int va[4], vb[2];
-        big_voffsets<TM, A_KCONTIG>(lda, m0, M, tid, va);
-        big_voffsets<TN, B_KCONTIG>(ldb, n0, N, tid, vb);
-        auto fetch = [&](int k0) {
-            const bool fast = k0 + BK <= kend;
-            big_load<TM, A_KCONTIG>(rsa, va, lda, m0, M, k0, kend, tid, fast, ra);
-            big_load<TN, B_KCONTIG>(rsb, vb, ldb, n0, N, k0, kend, tid, fast, rb);
-        };
-        auto stash = [&](int buf) {
-            big_store<TM, A_KCONTIG>(lds3 + buf * BUF, tid, ra);
-            big_store<TN, B_KCONTIG>(lds3 + buf * BUF + BK * PA, tid, rb);
-        };
-        __syncthreads();
-        fetch(kbeg);
-        stash(0);
-        if (nslab > 1) {
-            fetch(kbeg + BK);
-            stash(1);
-        }
-        if (nslab > 2) fetch(kbeg + 2 * BK);
-        __syncthreads();
-        const int aoff = wm * 128 + lr + lh * PA, boff = BK * PA + wn * 64 + lr + lh * PB;
-        float pa[4], pb[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pa[i] = lds3[aoff + 32 * i];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) pb[j] = lds3[boff + 32 * j];
-        int cur = 0;
-        for (int s = 0; s < nslab; ++s) {
-            const float* as = lds3 + cur * BUF + aoff;
-            const float* bs = lds3 + cur * BUF + boff;
-            const int nxt = cur == 2 ? 0 : cur + 1, nx2 = nxt == 2 ? 0 : nxt + 1;
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float a[4], b[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = pa[i];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = pb[j];
-                if (kk + 2 < BK) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pa[i] = as[(kk + 2) * PA + 32 * i];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) pb[j] = bs[(kk + 2) * PB + 32 * j];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     // next pair's operand reads (ds_read2 x 3) ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);     // ... then this pair's eight MFMAs
-                if (kk == BK - 6 && s + 2 < nslab) {
-                    stash(nx2);
-                    if (s + 3 < nslab) fetch(kbeg + (s + 3) * BK);
-                }
-            }
-            if (s + 1 < nslab) {
-                const float* an = lds3 + nxt * BUF + aoff;
-                const float* bn = lds3 + nxt * BUF + boff;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pa[i] = an[32 * i];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) pb[j] = bn[32 * j];
-            }
-            __syncthreads();
-            cur = nxt;
-        }
-        const bool atomic = !is_dp;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + lr;
-                if (n >= N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < M) {
-                        float* c = C + (size_t)m * ldc + n;
-                        if (atomic)
-                            atomicAdd(c, acc[i][j][r]);
-                        else
-                            *c = acc[i][j][r];
-                    }
-                }
-            }
-    }
-}
-
-// ----------------------------------------------------------------------------------------------------------
 // fp32 GEMM on the bf16 matrix pipe: error-free operand splitting.
 //
 // Every fp32 operand element is written as a = a1 + a2 + a3 with a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
@@ -966,42 +760,9 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
     const bool vec0 = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
                       ((!AK && !BKc) || K % 4 == 0);
     static const bool v2_on = !(getenv("DS2_GEMM_V2") && getenv("DS2_GEMM_V2")[0] == '0');    // A/B timing switch
-    // DS2_GEMM_V3: 0 = never, 1 = whenever eligible, default = when there are at least two full rounds of 256 x 128 tiles
-    // (measured: 4096^3 134 vs 124 TFLOP/s for the 128 x 128 kernel, but on ONE round of tiles -- the B = 10 model shapes --
-    // every workgroup's prologue and 128 KB epilogue fall together and the smaller tile with stream-K runs wins)
-    static const int v3_mode = getenv("DS2_GEMM_V3") ? atoi(getenv("DS2_GEMM_V3")) : 2;
-    const bool v3_fit = v3_mode == 1 || (v3_mode == 2 && ds2_cdiv(M, 256) * tn >= 2 * gemm_slots());
-    if (split_k == 1 && v3_fit && beta == 0.f && vec0 && (AK || (M & 3) == 0) && (BKc || (N & 3) == 0) && M >= 1024) {
-        const unsigned long long abytes = 4ull * (AK ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
-        const unsigned long long bbytes = 4ull * (BKc ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
-        if (abytes >= 0x7FFFFFF0ull || bbytes >= 0x7FFFFFF0ull) return -1;
-        const int tm3 = ds2_cdiv(M, 256), tiles = tm3 * tn, slots = gemm_slots(), nslab = ds2_cdiv(K, BK);
-        int dp = tiles, sk_wgs = 0, sk_units = 0, sk_total = 0;
-        const int rem = tiles % slots;
-        if (rem != 0 && nslab >= 16) {
-            dp = tiles - rem;
-            sk_total = rem * nslab;
-            sk_wgs = sk_total / 16 < slots ? sk_total / 16 : slots;
-            if (sk_wgs < 1) sk_wgs = 1;
-            sk_units = ds2_cdiv(sk_total, sk_wgs);
-            if (sk_units > nslab) sk_units = nslab;
-            sk_wgs = ds2_cdiv(sk_total, sk_units);
-            const int r0 = (dp / tn) * 256;
-            zero_rows(C + (size_t)r0 * ldc, ldc, N, M - r0, st);
-        }
-        const size_t lds = (size_t)3 * BK * (256 + 4 + 128 + 4) * sizeof(float);
-        static bool attr_set[4] = {false, false, false, false};
-        const int which = (AK ? 2 : 0) + (BKc ? 1 : 0);
-        if (!attr_set[which]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_v3_kernel<AK, BKc>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return -1;
-            attr_set[which] = true;
-        }
-        hipLaunchKernelGGL((gemm_f32_v3_kernel<AK, BKc>), dim3(dp + sk_wgs), dim3(256), lds, st, M, N, K, A, lda, B, ldb, C,
-                           ldc, tn, dp, sk_units, sk_total, (unsigned int)abytes, (unsigned int)bbytes);
-        return 0;
-    }
+    // (a 256 x 128 kernel with three LDS slab buffers for this family -- gemm_f32_v3_kernel, round 2: 134 against 124 TFLOP/s on
+    // 4096^3, behind the stream-K kernel on the model's one-round shapes -- went when the split-operand family became the
+    // default; removed in round 5)
     const int tiles_all = tm * tn, slots_all = gemm_slots();
     if (split_k == 1 && v2_on && tiles_all > slots_all && tiles_all % slots_all != 0 && ds2_cdiv(K, BK) >= 16 && beta == 0.f) {
         // whole-tile workgroups for as many complete rounds of the resident slots as there are, stream-K runs for the rest

@@ -230,20 +230,17 @@ def _conv_ref(which, x, w, b):
     return F.conv2d(x, w, b, stride=(2, 1))
 
 
-@pytest.mark.parametrize('which,bsz,t_in,wlds', [(1, 2, 121, '0'), (1, 3, 64, '0'), (2, 2, 66, '0'), (2, 1, 43, '0'),
-                                                 (1, 1, 301, '0'), (2, 2, 66, '1'), (2, 3, 139, '1'), (2, 1, 43, '1'),
+@pytest.mark.parametrize('which,bsz,t_in,form', [(1, 2, 121, '0'), (1, 3, 64, '0'), (2, 2, 66, '0'), (2, 1, 43, '0'),
+                                                 (1, 1, 301, '0'), (2, 3, 139, '0'),
                                                  (2, 2, 66, 'dgrad-split'), (2, 3, 139, 'dgrad-split'), (2, 1, 43, 'dgrad-split'),
                                                  (2, 4, 301, 'dgrad-split'), (2, 1, 1060, 'dgrad-split')])
-def test_conv_fwd_bwd(ops, monkeypatch, which, bsz, t_in, wlds):
-    """(wlds = '1': conv2's direct forward kernel in the filter-through-LDS form, which large batches select by themselves;
-    'dgrad-split': the data gradient through the gather kernel on the bf16 matrix pipe, csrc/conv_split.hip, which the
-    forward pass uses by default.  The direct forward kernels are covered by test_conv2_forward_families_agree.
+def test_conv_fwd_bwd(ops, monkeypatch, which, bsz, t_in, form):
+    """('dgrad-split': the data gradient through the gather kernel on the bf16 matrix pipe, csrc/conv_split.hip, which the
+    forward pass uses by default.  The direct forward kernel is covered by test_conv2_forward_families_agree.
     B = 1, t1 = 1060: the even-row launch (31 rows) has 1024+ waves and does not split K, the odd-row launch (30 rows) has
     fewer and does -- the output's one zero fill must precede BOTH (round 3's second launch wiped the first one's rows).)"""
-    if wlds == 'dgrad-split':
+    if form == 'dgrad-split':
         monkeypatch.setenv('DS2_CONV_SPLIT_DGRAD', '1')
-        wlds = '0'
-    monkeypatch.setenv('DS2_CONV_WLDS', wlds)
     rng = np.random.default_rng(10 * which + bsz)
     cin, fin, kf = (1, 161, 41) if which == 1 else (32, 61, 21)
     x = torch.from_numpy(rng.standard_normal((bsz, cin, fin, t_in)).astype(np.float32)).requires_grad_(True)
@@ -351,7 +348,7 @@ def test_conv_wgrad_families_agree(ops, monkeypatch, which, bsz, t_in):
 @pytest.mark.parametrize('bsz,t1', [(2, 56), (1, 33), (3, 129), (10, 150), (6, 400), (2, 1501 // 2)])
 def test_conv2_forward_families_agree(ops, monkeypatch, bsz, t1):
     """conv2's forward pass three ways against torch: the gather kernel on the bf16 matrix pipe (default; 6 and 9 partial
-    products; 32 or 64 positions per wave depending on the number of positions) and the two direct kernels on the f32-input
+    products; 32 or 64 positions per wave depending on the number of positions) and the direct kernel on the f32-input
     matrix instruction.  Error relative to sum |w||x| as in the GEMM family test: the split kernels no worse than the
     direct ones."""
     torch.manual_seed(bsz * 1000 + t1)
@@ -362,16 +359,15 @@ def test_conv2_forward_families_agree(ops, monkeypatch, bsz, t1):
     scale = F.conv2d(x.double().abs(), w.double().abs(), b.double().abs(), stride=(2, 1))
     err = {}
     for name, env in (('split6', {'DS2_CONV_SPLIT': '6'}), ('split9', {'DS2_CONV_SPLIT': '9'}),
-                      ('direct', {'DS2_CONV_SPLIT': '0', 'DS2_CONV_WLDS': '0'}),
-                      ('direct-wlds', {'DS2_CONV_SPLIT': '0', 'DS2_CONV_WLDS': '1'})):
+                      ('direct', {'DS2_CONV_SPLIT': '0'})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         out = ops.conv_fwd(2, x, w, b, t1)
         assert out.shape == ref.shape
         err[name] = float(((out.double() - ref).abs() / scale).max())
-    assert err['direct'] <= 2e-6 and err['direct-wlds'] <= 2e-6, err
-    assert err['split6'] <= 1.25 * max(err['direct'], err['direct-wlds']) + 1e-8, err
-    assert err['split9'] <= 1.25 * max(err['direct'], err['direct-wlds']) + 1e-8, err
+    assert err['direct'] <= 2e-6, err
+    assert err['split6'] <= 1.25 * err['direct'] + 1e-8, err
+    assert err['split9'] <= 1.25 * err['direct'] + 1e-8, err
 
 
 # ------------------------------------------------------------------------------------------- BN
