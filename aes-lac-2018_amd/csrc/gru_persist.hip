@@ -78,7 +78,7 @@ constexpr int NSHARD = 8;  // arrival counters per direction (workgroup x -> sha
                            // 100 arrivals on ONE word serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
 struct SyncWs {            // lives in caller-provided device memory: zeroed ONCE by the caller when it is allocated (and
                            // again after a reported timeout); every launch that completes leaves the counters zero
-    unsigned int arrive[2][4][NSHARD][32];   // [direction][batch part (batch-split forms: up to four)][shard][line]
+    unsigned int arrive[2][3][NSHARD][32];   // [direction][batch part (backward batch-split forms)][shard][line]
     unsigned int done[32];   // workgroups that have left the kernel; the last one zeroes arrive[] and done for the next launch
     unsigned int error;      // set to 1 on a spin timeout; STICKY: only the host clears it (ops.raise_async_error)
 };
@@ -112,7 +112,7 @@ __device__ __forceinline__ void leave_kernel(SyncWs* sync) {
     const unsigned int prev = __hip_atomic_fetch_add(&sync->done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == total - 1) {
         unsigned int* a = &sync->arrive[0][0][0][0];
-        for (int i = 0; i < 2 * 4 * NSHARD; ++i) __hip_atomic_store(a + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 2 * 3 * NSHARD; ++i) __hip_atomic_store(a + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&sync->done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -2009,248 +2009,6 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent5_kernel(float* __
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// Backward recurrence for 17 <= B <= 48, the broadcast deal with 32 units and a QUARTER of the batch per workgroup (round 5).
-//
-// What bounds gru_bwd_persistent_p2_kernel (16 units, half the batch: 200 workgroups) at B = 32 is not the matrix pipe (43 %
-// busy) but the hand-off: every workgroup pulls its part's whole d(gh) -- 16 rows x 2400 k x 4 B = 150 KB -- through its CU's
-// vector-memory path every step, at ~25 B/clk (profiles/r04_pmc_sq_gru_T405_B32.txt).  Bytes pulled per multiply-add are
-// 4 / (units per workgroup): twice the units and half the rows is the same matrix work per workgroup and HALF the bytes --
-// but 8 rows fill only half of a 16x16x4 tile.  On v_mfma_f32_4x4x1_16b_f32 they are two batch quads with no padding:
-// A = d(gates) of one batch quad at one k, broadcast to 8 blocks (CBSZ = 3), B = weights, blocks 0-7 = the 8 row groups at
-// k sub-index 0, blocks 8-15 = the same row groups at k sub-index 1: an instruction retires 2 k x 32 units x 4 batch rows,
-// 160 instructions per wave and batch quad (K = 2400 padded to 2560), and a wave holds complete sums over its k for BOTH
-// lane halves: 16 partials per output (wave x lane half), no fold.  Grid: 25 slices x 2 directions x 4 parts = 200.
-// Counted, drained hand-off (gru_bwd_persistent4_kernel<.., PROTO = 0>): with more than one quad per workgroup the canaries
-// of the speculative protocol cost more stores than the protocol saves.
-// ----------------------------------------------------------------------------------------------------------
-template <int NGI, int NQ>
-__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __restrict__ G, float* __restrict__ ghn,
-                                                                       const float* __restrict__ hout,
-                                                                       const float* __restrict__ d_out,
-                                                                       const float* __restrict__ w_hh_t,
-                                                                       SyncWs* __restrict__ sync, float* __restrict__ ring,
-                                                                       int T, int B, int H, int dbg) {
-    static_assert(NQ >= 1 && NQ <= 3, "one to three batch quads per workgroup");
-    constexpr int NPART = 4, UNITS = 32, NSLOT = 2;
-    constexpr int GP = NQ <= 2 ? 2 : 1;                 // gate threads per (unit, batch row): 32 x 4 NQ x GP <= 512
-    // [batch row 4 NQ][unit 32][16 partials = (wave, lane half), rotated by (unit >> 1): the 32 lanes of a store hit 32 banks]
-    __shared__ __attribute__((aligned(16))) float red6[NQ * 4 * UNITS * 16];
-    __shared__ int abort_flag;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
-    const int j0 = blockIdx.x * UNITS;
-    const int blk = lane >> 2, li = lane & 3, rg = blk & 7, ksub = blk >> 3;
-    const int K = 3 * H;
-    const int bper = (B + NPART - 1) / NPART;
-    const int b0 = part * bper;
-    const int nb = min(bper, B - b0);                   // <= 4 NQ (the launcher)
-    const int ncg = (nb + 3) >> 2;
-    const int ng = (K + 63) >> 6;
-    const int slot_floats = ng * 64 * nb;               // a partial last quad keeps only its nb & 3 rows
-    float* my_ring = ring + (size_t)(dir * NPART + part) * NSLOT * ((size_t)ng * 64 * bper);
-    if (nb <= 0) {
-        if (tid == 0) leave_kernel(sync);
-        return;
-    }
-    if (tid == 0) abort_flag = 0;
-
-    // resident weights (B operands): unit j0 + 4 rg + li at k = 64 G + 32 ksub + 4 a + e (component e)
-    f32x4 wreg[NGI][8];
-    {
-        const int unit = j0 + 4 * rg + li;
-        const float* row = unit < H ? w_hh_t + ((size_t)dir * H + unit) * K : nullptr;
-#pragma unroll
-        for (int gi = 0; gi < NGI; ++gi)
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const int k = 64 * (wave + NWP * gi) + 32 * ksub + 4 * a;
-                wreg[gi][a] = (row && k < K) ? *reinterpret_cast<const f32x4*>(row + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-    }
-    // gate role: lane = (unit in quad u4, gpart gp); GP = 2: a wave = ONE batch row of all 32 units
-    const int u4 = tid & 3, gp = GP == 2 ? (tid >> 2) & 1 : 0;
-    const int rest = tid >> (GP == 2 ? 3 : 2), uq = rest & 7, nn = rest >> 3;
-    const int gb = b0 + nn, gj = j0 + 4 * uq + u4;
-    const bool gate_ok = (nn < nb) && (gj < H);
-    float dhz = 0.f;
-    unsigned int* shards = &sync->arrive[dir][part][0][0];
-    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
-    // hand-off: lane u4 == 0 stores the quad's four units of one gate as 16 bytes (k index of unit j in gate g is g H + j):
-    // GP = 2: gpart 0 the gates r and z, gpart 1 the gate n; GP = 1: all three
-    const bool storer = gate_ok && u4 == 0;
-    const int rows4g = min(4, nb - (nn & ~3)) * 4;      // floats per k quad of this thread's batch quad
-    const int hbase = (nn >> 2) * ng * 256 + (nn & 3) * 4;
-    int ho[3];
-#pragma unroll
-    for (int g3 = 0; g3 < 3; ++g3) ho[g3] = hbase + ((g3 * H + gj) >> 2) * rows4g;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, NSLOT * slot_floats * 4, 0x00020000);
-    __syncthreads();
-    int scur = 0, sprev = NSLOT - 1;
-
-    // byte offsets of this lane's hand-off loads inside a slot (rows past the batch / k past K / quads past the part: nothing)
-    int loff[NQ][NGI];
-#pragma unroll
-    for (int cg = 0; cg < NQ; ++cg) {
-        const int rows = min(4, nb - 4 * cg);
-#pragma unroll
-        for (int gi = 0; gi < NGI; ++gi) {
-            const int gg = wave + NWP * gi;
-            loff[cg][gi] = (cg < ncg && 64 * gg + 4 * blk < K && li < rows) ? (cg * ng * 256 + ((gg * 16 + blk) * rows + li) * 4) * 4
-                                                                            : OOB_OFFSET;
-        }
-    }
-    // partial sums: value (batch row, unit), position (wave, lane half) rotated by unit >> 1
-    const int un = 4 * rg + li;
-    float* const red_w = red6 + un * 16 + ((wave * 2 + ksub + (un >> 1)) & 15);
-    const float* const red_r = red6 + (nn * UNITS + 4 * uq + u4) * 16 + (GP == 2 ? 8 * gp : 0);
-
-    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
-    const long long tstep = dir == 0 ? -1 : 1;
-    const long long dG = tstep * B * 6 * H, dD = tstep * B * H, dN = tstep * B * 2 * H;
-    const int t_first = dir == 0 ? T - 1 : 0;
-    size_t of_g = (((size_t)t_first * B + gb) * 2 + dir) * 3 * H + gj;            // G[of_g + g H]: gate g of step t
-    size_t of_d = ((size_t)t_first * B + gb) * H + gj;                            // d_out
-    size_t of_n = (((size_t)t_first * B + gb) * 2 + dir) * H + gj;                // ghn
-    size_t of_h = (((size_t)dir * T + t_first + tstep) * B + gb) * H + gj;        // hout of the step BEFORE t in forward time order
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? T - 1 - s : s;
-        auto early_loads = [&](int next) {
-            dh = r = z = n = gn = hpv = 0.f;
-            if (gate_ok) {
-                const int tt = t + (next ? (int)tstep : 0);
-                const bool has_prev = dir == 0 ? (tt > 0) : (tt < T - 1);
-                const size_t g0 = of_g + (next ? dG : 0);
-                dh = d_out[of_d + (next ? dD : 0)];
-                r = G[g0];
-                z = G[g0 + H];
-                n = G[g0 + 2 * H];
-                gn = ghn[of_n + (next ? dN : 0)];
-                if (has_prev) hpv = hout[of_h + (next ? dD : 0)];
-            }
-        };
-        if (s == 0) early_loads(0);
-        if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0) abort_flag = 1;
-            __syncthreads();
-            if (abort_flag) return;
-            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-                my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
-            f32x4 bf[NQ][NGI];
-#pragma unroll
-            for (int gi = 0; gi < NGI; ++gi)               // k-group major: the MFMAs below consume in this order
-#pragma unroll
-                for (int cg = 0; cg < NQ; ++cg) bf[cg][gi] = LOAD_HANDOFF(rs_x, loff[cg][gi]);
-            __builtin_amdgcn_sched_barrier(0);             // every load out before the first MFMA
-            f32x4 acc[NQ][2];
-#pragma unroll
-            for (int cg = 0; cg < NQ; ++cg) acc[cg][0] = acc[cg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!DS2_DBG(dbg, 2)) {
-#pragma unroll
-                for (int gi = 0; gi < NGI; ++gi)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        static_for<0, 8>([&](auto a_tag) {
-                            constexpr int a = decltype(a_tag)::value;
-#pragma unroll
-                            for (int cg = 0; cg < NQ; ++cg)
-                                acc[cg][a & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(bf[cg][gi][e], wreg[gi][a][e], acc[cg][a & 1], 3, a, 0);
-                        });
-            }
-            // D register i = batch row i of quad cg; lane (blk, li): unit 4 rg + li, k sub-index ksub
-#pragma unroll
-            for (int cg = 0; cg < NQ; ++cg) {
-                const f32x4 sum = acc[cg][0] + acc[cg][1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) red_w[((cg * 4 + i) * UNITS) * 16] = sum[i];
-            }
-        }
-        __syncthreads();
-        float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
-        {
-            float part = 0.f;
-            if (s > 0 && nn < 4 * NQ) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(red_r);
-                f32x4 ps = src[0] + src[1];
-                if constexpr (GP == 1) ps += src[2] + src[3];
-                part = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            }
-            if constexpr (GP == 2) {                       // the two gparts of a unit sit 4 lanes apart
-                const float up = dpp_row_shl<4>(part), dn = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part), 0x114, 0xF, 0xF, true));
-                part += gp ? dn : up;
-            }
-            if (gate_ok) {
-                dh += part + dhz;
-                const float dn_pre = dh * (1.f - z) * (1.f - n * n);
-                const float dz_pre = dh * (hpv - n) * z * (1.f - z);
-                const float dr_pre = dn_pre * gn * r * (1.f - r);
-                dhz = dh * z;
-                sv_r = dr_pre;
-                sv_z = dz_pre;
-                sv_n = dn_pre;
-                sv_g = dn_pre * r;
-            }
-        }
-        {
-            // the quad's four units of one gate to its first lane: 16-byte write-through stores into the ring
-            auto quad4 = [&](float v) {
-                f32x4 o;
-                o[0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x00, 0xF, 0xF, true));
-                o[1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55, 0xF, 0xF, true));
-                o[2] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xAA, 0xF, 0xF, true));
-                o[3] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xFF, 0xF, 0xF, true));
-                return o;
-            };
-            const int sbase = scur * slot_floats;
-            // (dbg bit 6, fault-injection builds: workgroup 0 'loses' its arrival of step 2 -- below)
-            if constexpr (GP == 2) {
-                const f32x4 va = quad4(gp == 0 ? sv_r : sv_g), vb = quad4(sv_z);
-                if (storer) {
-                    store_sc1_b128(rs_w, (sbase + ho[gp == 0 ? 0 : 2]) * 4, __builtin_bit_cast(u32x4, va));
-                    if (gp == 0) store_sc1_b128(rs_w, (sbase + ho[1]) * 4, __builtin_bit_cast(u32x4, vb));
-                }
-            } else {
-                const f32x4 v0 = quad4(sv_r), v1 = quad4(sv_z), v2 = quad4(sv_g);
-                if (storer) {
-                    store_sc1_b128(rs_w, (sbase + ho[0]) * 4, __builtin_bit_cast(u32x4, v0));
-                    store_sc1_b128(rs_w, (sbase + ho[1]) * 4, __builtin_bit_cast(u32x4, v1));
-                    store_sc1_b128(rs_w, (sbase + ho[2]) * 4, __builtin_bit_cast(u32x4, v2));
-                }
-            }
-        }
-        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();            // every storing wave drains its hand-off stores
-        sprev = scur;
-        scur ^= 1;
-        __syncthreads();
-        if (tid == 0 && !(DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0))
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
-            if constexpr (GP == 2) {
-                if (gp == 0) {
-                    G[of_g] = sv_r;
-                    G[of_g + H] = sv_z;
-                } else {
-                    G[of_g + 2 * H] = sv_n;
-                    ghn[of_n] = sv_g;
-                }
-            } else {
-                G[of_g] = sv_r;
-                G[of_g + H] = sv_z;
-                G[of_g + 2 * H] = sv_n;
-                ghn[of_n] = sv_g;
-            }
-        }
-        if (s + 1 < T) early_loads(1);                  // the next step's saved activations, behind this step's stores
-        of_g += dG;
-        of_d += dD;
-        of_n += dN;
-        of_h += dD;
-    }
-    if (tid == 0) leave_kernel(sync);
-}
-
-// ----------------------------------------------------------------------------------------------------------
 // Forward recurrence on v_mfma_f32_4x4x1_16b_f32 with A-operand broadcast (CBSZ / ABID; tools/mfma4x4_bcast_probe.hip:
 // blocks are grouped 2^CBSZ at a time and every block of a group takes its A rows from the group's block ABID).
 //
@@ -3270,29 +3028,6 @@ bool launch_bwd_persistent5(float* G, float* ghn, const float* hout, const float
     return false;
 }
 
-// 32 units, a quarter of the batch (gru_bwd_persistent6_kernel): 17 <= B <= 48
-template <int NQ>
-bool launch_bwd_persistent6(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
-                            SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
-    const int opts[] = {1, 2, 3, 5};
-    const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
-    dim3 grid(ds2_cdiv(H, 32), 2, 4), block(NWP * 64);
-#define DS2_BWD6_CASE(K)                                                                                         \
-    case K:                                                                                                      \
-        if (!grid_is_coresident(&gru_bwd_persistent6_kernel<K, NQ>, grid, 0)) return false;                     \
-        hipLaunchKernelGGL((gru_bwd_persistent6_kernel<K, NQ>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, sync, ring, \
-                           T, B, H, dbg);                                                                        \
-        return true;
-    switch (ngi) {
-        DS2_BWD6_CASE(1)
-        DS2_BWD6_CASE(2)
-        DS2_BWD6_CASE(3)
-        DS2_BWD6_CASE(5)
-    }
-#undef DS2_BWD6_CASE
-    return false;
-}
-
 // Co-residency: every workgroup of a persistent launch spins on arrivals from all the others, so the whole grid must be
 // on the chip at once.  The budget is 15/16 of the CURRENT device's compute units (240 of an MI355X's 256: the rest
 // stays free for a concurrent RCCL kernel or the side stream), read once per device; a partitioned (CPX) or smaller
@@ -3386,9 +3121,8 @@ inline size_t ring_floats(int B, int H) {
     const int tiles16 = ds2_cdiv(B, 16) > 2 * ds2_cdiv(ds2_cdiv(B, 2), 16) ? ds2_cdiv(B, 16) : 2 * ds2_cdiv(ds2_cdiv(B, 2), 16);
     const size_t a = (size_t)tiles16 * (size_t)(3 * H / 16) * 256 * 3 / 2 + 4096;     // 16x16 forms (whole batch / two parts;
                                                                                       // three bf16 planes per value in the split forms)
-    const size_t b2 = (size_t)2 * ds2_cdiv(B, 2), b3 = (size_t)3 * ds2_cdiv(B, 3), b4 = (size_t)4 * ds2_cdiv(B, 4);
-    const size_t b23 = b2 > b3 ? b2 : b3;
-    const size_t b = (b23 > b4 ? b23 : b4) * (size_t)ds2_cdiv(3 * H, 64) * 64;        // 4x4x1 forms (1-4 batch parts)
+    const size_t b2 = (size_t)2 * ds2_cdiv(B, 2), b3 = (size_t)3 * ds2_cdiv(B, 3);
+    const size_t b = (b2 > b3 ? b2 : b3) * (size_t)ds2_cdiv(3 * H, 64) * 64;          // 4x4x1 forms (1-3 batch parts)
     return (size_t)2 * (2 * a > 4 * b ? 2 * a : 4 * b);                              // two slots / up to four (canary protocols)
 }
 
@@ -3537,18 +3271,12 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
 #define DS2_BWD4_GO(R_)                                                                                             \
     (proto != 0 ? launch_bwd_persistent4<R_, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)           \
                 : launch_bwd_persistent4<R_, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
-    // 17 <= B <= 48: 32 units and a quarter of the batch per workgroup on the 4x4x1 instruction (half the hand-off bytes of
-    // the two-part 16x16x4 form per multiply-add); DS2_GRU_BWD_Q4 = 0 / 1 forces it off / on (A/B timing)
-    const char* q4e = getenv("DS2_GRU_BWD_Q4");
-    const bool q4 = (q4e ? q4e[0] == '1' : false) && !(form && form[0] == '4') && B >= 17 && B <= 48 && H % 4 == 0 &&
-                    8 * ds2_cdiv(H, 32) <= max_persistent_wgs() && ngi_ok;
-    if (q4 && !((ds2_cdiv(B, 4) + 3) / 4 > 2 && ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) > 3)) {   // (three quads x five k groups: registers)
-        const int nq = (ds2_cdiv(B, 4) + 3) / 4;
-        ok = nq == 1 ? launch_bwd_persistent6<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
-           : nq == 2 ? launch_bwd_persistent6<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
-                     : launch_bwd_persistent6<3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-    }
-    else if (p2)
+    // (round 5, measured and removed: 17 <= B <= 32 on the 4x4x1 instruction with 32 units and a QUARTER of the batch per
+    // workgroup -- half the hand-off bytes of the two-part form per multiply-add, counted hand-off -- B = 32 / 24 / 17: 5.00 /
+    // 4.70 / 4.52 us per step against 4.74 / 4.58 / 4.48: the 4x4x1 instruction retires a multiply-add in 10 cycles / 256 where
+    // the 16x16x4 one takes 32 / 1024, and the bytes are not what bounds the two-part form: from B = 17 to 32 its part grows
+    // from 9 to 16 rows, 84 to 150 KB per workgroup and step, and the step by 0.26 us -- profiles/r05_recurrence_experiments.md)
+    if (p2)
         // (the backward twin is hand-off-bound, not matrix-bound -- three gates' values cross per step, and as bf16 planes
         // they are 1.5 x the bytes: 4.91 against 4.74 us per step at B = 32, 8.46 against 7.57 at B = 64; DS2_GRU_P2_BF16_BWD=1
         // selects it for A/B runs)
