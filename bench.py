@@ -822,12 +822,14 @@ def main():
     ach, dur, flop = roof['bwd']
     # HBM-side bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of the same shape whose
     # summary is committed under profiles/ (PMC collection cannot run inside this process); the file is named below
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_floor, traffic_alg = None, None, None, None
     for name in ('r05_traffic.json',):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
                 traffic = rec['backward_recurrence_launch']['traffic_bytes_per_launch']
+                traffic_floor = rec['backward_recurrence_launch'].get('xcd_replicated_floor_bytes_per_launch')
+                traffic_alg = rec['backward_recurrence_launch'].get('algorithmic_hbm_bytes_per_launch')
                 traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gru_step_timing.py, ' \
                               'not measured in this run)' % name
                 break
@@ -889,6 +891,12 @@ def main():
                                'BiGRU layer, both directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
+                     'traffic_algorithmic': traffic_alg,
+                     'traffic_floor_of_an_exchange_through_memory': traffic_floor,
+                     'traffic_note': 'bytes at the memory side per launch (2 x FETCH_SIZE + WRITE_SIZE).  traffic_algorithmic: the saved '
+                                     'activations once (an exchange that stayed on chip would move nothing else).  An exchange through memory '
+                                     'between CUs on EIGHT XCDs with non-coherent L2s cannot go below the payload fetched once into '
+                                     'EVERY XCD (traffic_floor_...): the ratio to that, not to the algorithmic bytes, is the waste',
                      'avg_launch_us': round(dur * 1e6, 1), 'us_per_time_step': round(dur * 1e6 / t_mean, 3),
                      'floor_us_per_step': floor,
                      'flop_per_launch': flop,
