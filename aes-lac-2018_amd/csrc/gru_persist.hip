@@ -2623,6 +2623,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
     }
     for (int s = 0; s < T; ++s) {
         DS2_WTICK(0);
+        DS2_WTICK(1);
         // where this step's payload and the canary two slots ahead go (scalar arithmetic, ahead of the matrix phase)
         const int pay_off = scur * slot_floats * 4 + hoff, can_off = ((scur + CAHEAD) & (NSLOT - 1)) * slot_floats * 4 + hoff;
         // (ablation bits, fault-injection / timing builds only -- results WRONG: 2 = no hand-off loads and no MFMAs (the step's

@@ -665,9 +665,12 @@ def main():
         inputs, pct = front(flat, offs)
         return trainer.update((inputs, labels, pct, lens), defer=True)
 
-    trainer.reserve(int(float(os.environ.get('DS2_BENCH_RESERVE_GB', '4')) * (1 << 30)))   # one allocator block up front
+    trainer.reserve(int(float(os.environ.get('DS2_BENCH_RESERVE_GB', '8')) * (1 << 30)))   # one allocator block up front (the longest
+    # bin needs ~2 GB per step in flight, twice that while the side stream still holds the previous step's buffers)
     note('model built, inputs resident; timing')
+    reserved0 = torch.cuda.memory_stats(dev).get('reserved_bytes.all.current', 0)
     dt, per, loss = timed_steps(step_sync, args.steps, args.warmup, use_dist)
+    reserved_growth = torch.cuda.memory_stats(dev).get('reserved_bytes.all.current', 0) - reserved0   # > 0: a hipMalloc inside the timed region
     note('timed region done (a host synchronisation in every step): %.2f ms/step' % (1e3 * dt / args.steps))
     idxs = [i % len(mine) for i in range(args.warmup, args.warmup + args.steps)]
     frames = float(sum(frames_of(mine[i]) for i in idxs))
@@ -875,7 +878,8 @@ def main():
                                          'p10': round(1e3 * pct_of(per_sorted, 0.1), 3),
                                          'p90': round(1e3 * pct_of(per_sorted, 0.9), 3),
                                          'max': round(1e3 * per_sorted[-1], 3),
-                                         'per_step': [round(1e3 * v, 2) for v in per]},
+                                         'per_step': [round(1e3 * v, 2) for v in per],
+                                         'allocator_growth_bytes_in_timed_region': int(reserved_growth)},
                    'frames_per_s_per_step_rank0': {'median': round(pct_of(step_rates, 0.5), 1),
                                                    'p10': round(pct_of(step_rates, 0.1), 1),
                                                    'p90': round(pct_of(step_rates, 0.9), 1)},
