@@ -1,5 +1,6 @@
 // Persistent BiGRU recurrence kernels for gfx950 (one launch per layer pass).
 #include <stddef.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -2748,8 +2749,14 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
 // between re-loads.  A failed attempt costs a full round trip and adds polling traffic from 1600 waves, so the first attempt
 // is timed to land just after the slowest producer's payload; measured optimum (tools/gru_sweep.py, B = 4 .. 12): the forward
 // kernel 8-12, the backward kernel (more and wider stores per producer) ~20.  DS2_GRU_SPEC_FWD / _BWD = "delay,backoff".
-inline int spec_timing(int bwd) {
-    int delay = bwd ? 14 : 10, backoff = 2;
+// def_inc / def_log2clean: the calling kernel's default adaptation policy (+inc sleeps after a step with a re-load, -1 after
+// 2^log2clean clean ones); def_delay >= 0: its default first-attempt delay.  Round 5: the row-deal forward kernel wants a SLOW
+// decay -- measured at B = 10 / 9 / 12, us per step, policy (1, 2) -> (1, 5) -> (1, 6): 2.33 / 2.20 / 2.40 -> 2.16 / 2.08 / 2.17
+// -> 2.14 / 2.09 / 2.14 (a fixed delay of 6-8 sleeps without adaptation: 2.09-2.10) -- with the fast decay the delay creeps
+// down until a wave re-loads (17 % of wave-steps did), and a re-load costs this kernel more than a few sleeps too many; the
+// older kernels (B = 4 / 8) lose with the slow decay (forward 1.65 -> 1.75 / backward 2.32 -> 2.50) and keep (1, 2).
+inline int spec_timing(int bwd, int def_delay = -1, int def_inc = 1, int def_log2clean = 2) {
+    int delay = def_delay >= 0 ? def_delay : (bwd ? 14 : 10), backoff = 2;
     const char* e = getenv(bwd ? "DS2_GRU_SPEC_BWD" : "DS2_GRU_SPEC_FWD");
     if (e) {
         delay = atoi(e);
@@ -2759,7 +2766,7 @@ inline int spec_timing(int bwd) {
     int adaptive = 1;                                  // bit 0: adapt the sleep count; bit 1: self-timed (wait for the own stores' acks)
     const char* a = getenv("DS2_GRU_SPEC_ADAPT");
     if (a) adaptive = atoi(a);
-    int inc = 1, log2clean = 2;                        // adaptation: +inc after a step with a re-load, -1 after 2^log2clean clean ones
+    int inc = def_inc, log2clean = def_log2clean;      // adaptation: +inc after a step with a re-load, -1 after 2^log2clean clean ones
     const char* pol = getenv("DS2_GRU_SPEC_POLICY");
     if (pol) {
         inc = atoi(pol);
@@ -2973,7 +2980,10 @@ bool launch_fwd_persistent5(float* G, float* ghn, float* hout, const float* w_hh
     dim3 grid(ds2_cdiv(H, UNITS), 2, P), block(NWP * 64);
     auto kern = &gru_fwd_persistent5_kernel<KW, UNITS, P>;
     if (!grid_is_coresident(kern, grid, 0)) return false;
-    hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, spec_timing(0));
+    // (first-attempt delay and adaptation policy of THIS kernel: DS2_GRU_FWD5_SPEC = "delay,inc,log2clean" for A/B runs)
+    int d = 8, inc = 1, l2c = 6;
+    if (const char* e = getenv("DS2_GRU_FWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
+    hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, spec_timing(0, d, inc, l2c));
     return true;
 }
 
@@ -3013,11 +3023,16 @@ bool launch_bwd_persistent5(float* G, float* ghn, const float* hout, const float
     const int opts[] = {1, 2, 3, 5};
     const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
     dim3 grid(ds2_cdiv(H, 4 * NRG), 2, 3), block(NWP * 64);
+    // (first-attempt delay and adaptation policy of THIS kernel: DS2_GRU_BWD5_SPEC = "delay,inc,log2clean" for A/B runs)
+    // (measured at B = 10, us per step, (14, 1, 2) -> (10, 1, 4): 28 units 2.95 -> 2.86, 24 units 2.74 -> 2.65)
+    int d = 10, inc = 1, l2c = 4;
+    if (const char* e = getenv("DS2_GRU_BWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
+    const int spec = spec_timing(1, d, inc, l2c);
 #define DS2_BWD5_CASE(K)                                                                                         \
     case K:                                                                                                      \
         if (!grid_is_coresident(&gru_bwd_persistent5_kernel<K, NRG>, grid, 0)) return false;                     \
         hipLaunchKernelGGL((gru_bwd_persistent5_kernel<K, NRG>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, sync, ring, \
-                           T, B, H, dbg, spec_timing(1));                                                         \
+                           T, B, H, dbg, spec);                                                                  \
         return true;
     switch (ngi) {
         DS2_BWD5_CASE(1)
