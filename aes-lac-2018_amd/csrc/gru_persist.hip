@@ -3028,8 +3028,9 @@ bool launch_bwd_persistent5(float* G, float* ghn, const float* hout, const float
     const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
     dim3 grid(ds2_cdiv(H, 4 * NRG), 2, 3), block(NWP * 64);
     // (first-attempt delay and adaptation policy of THIS kernel: DS2_GRU_BWD5_SPEC = "delay,inc,log2clean" for A/B runs)
-    // (measured at B = 10, us per step, (14, 1, 2) -> (10, 1, 4): 28 units 2.95 -> 2.86, 24 units 2.74 -> 2.65)
-    int d = 10, inc = 1, l2c = 4;
+    // (measured at B = 10, us per step, (14, 1, 2) -> (10, 1, 4): 28 units 2.95 -> 2.86, 24 units 2.74 -> 2.65; 20 units
+    // 2.67-2.69 -> 2.54, and 2.51 with (10, 1, 5) -- with that the broadcast deal beats the 16-k-blocks deal's 2.61-2.64 there too)
+    int d = 10, inc = 1, l2c = NRG == 5 ? 5 : 4;
     if (const char* e = getenv("DS2_GRU_BWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
     const int spec = spec_timing(1, d, inc, l2c);
 #define DS2_BWD5_CASE(K)                                                                                         \
@@ -3314,12 +3315,12 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
         const int g20 = 6 * ds2_cdiv(H, 20), g24 = 6 * ds2_cdiv(H, 24), g28 = 6 * ds2_cdiv(H, 28);
         // the broadcast deal (gru_bwd_persistent5_kernel) where a part is one batch quad and H a multiple of 4;
         // DS2_GRU_BWD_BCAST = 0: the 16-k-blocks deal (A/B timing)
-        // (measured stand-alone at B = 10, us per step, 16-k-blocks -> broadcast deal: 28 units 3.02-3.05 -> 2.92, 24 units
-        // 2.79-2.81 -> 2.72, 20 units 2.61-2.64 -> 2.67-2.69: the widest form keeps the old deal unless DS2_GRU_BWD_BCAST = 1)
+        // (measured stand-alone at B = 10, us per step, 16-k-blocks -> broadcast deal, each with its own hand-off timing:
+        // 28 units 3.02-3.05 -> 2.86, 24 units 2.79-2.81 -> 2.65, 20 units 2.61-2.64 -> 2.51-2.54)
         const char* bc = getenv("DS2_GRU_BWD_BCAST");
         const bool bcast = H % 4 == 0 && ds2_cdiv(B, 3) <= 4 && !(bc && bc[0] == '0');
         if (g20 <= max_persistent_wgs() && g20 > g24 && cus - g20 >= want)                                     // 240 workgroups
-            ok = (bcast && bc && bc[0] == '1') ? launch_bwd_persistent5<5>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
+            ok = bcast ? launch_bwd_persistent5<5>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
                        : launch_bwd_persistent4<5, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
         else if (cus - g24 >= want || g28 >= g24)                                                               // 204
             ok = bcast ? launch_bwd_persistent5<6>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
