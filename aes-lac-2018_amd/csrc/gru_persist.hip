@@ -3306,30 +3306,26 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
                                       : launch_bwd_persistent_p2b<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
                  : ((B + 1) / 2 <= 16 ? launch_bwd_persistent_p2<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
                                       : launch_bwd_persistent_p2<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st));
-    else if (use4 && ngi_ok && parts == 3 && proto != 0) {
+    else if (use4 && ngi_ok && parts == 3 && proto != 0 && ds2_cdiv(B, 3) <= 4) {   // (<= 4: also under a forced DS2_GRU_PROTO)
         // units per workgroup by the CUs to leave free (see above); DS2_GRU_BWD_WIDE = 0 / 1 / 2 forces 24 / 28 / 20 (A/B timing)
         const int cus = device_cus();
         int want = spare_cus < 0 ? 52 : spare_cus;
         const char* w = getenv("DS2_GRU_BWD_WIDE");
         if (w && w[0] >= '0' && w[0] <= '2') want = w[0] == '0' ? 52 : (w[0] == '1' ? 82 : 0);
         const int g20 = 6 * ds2_cdiv(H, 20), g24 = 6 * ds2_cdiv(H, 24), g28 = 6 * ds2_cdiv(H, 28);
-        // the broadcast deal (gru_bwd_persistent5_kernel) where a part is one batch quad and H a multiple of 4;
-        // DS2_GRU_BWD_BCAST = 0: the 16-k-blocks deal (A/B timing)
-        // (measured stand-alone at B = 10, us per step, 16-k-blocks -> broadcast deal, each with its own hand-off timing:
-        // 28 units 3.02-3.05 -> 2.86, 24 units 2.79-2.81 -> 2.65, 20 units 2.61-2.64 -> 2.51-2.54)
-        const char* bc = getenv("DS2_GRU_BWD_BCAST");
-        const bool bcast = H % 4 == 0 && ds2_cdiv(B, 3) <= 4 && !(bc && bc[0] == '0');
-        if (g20 <= max_persistent_wgs() && g20 > g24 && cus - g20 >= want)                                     // 240 workgroups
-            ok = bcast ? launch_bwd_persistent5<5>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
-                       : launch_bwd_persistent4<5, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-        else if (cus - g24 >= want || g28 >= g24)                                                               // 204
-            ok = bcast ? launch_bwd_persistent5<6>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
-                       : launch_bwd_persistent4<6, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-        else                                                                                                    // 174
-            ok = bcast ? launch_bwd_persistent5<7>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
-                       : launch_bwd_persistent4<7, 2, 3>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+        // the broadcast deal (gru_bwd_persistent5_kernel): H is a multiple of 16 and a part is one batch quad here.  Measured
+        // stand-alone at B = 10, us per step, against the 16-k-blocks deal it replaces (gru_bwd_persistent4_kernel<5, NRG, 2, 3>,
+        // removed in round 5), each with its own hand-off timing: 28 units 3.02-3.05 -> 2.86, 24 units 2.79-2.81 -> 2.65,
+        // 20 units 2.61-2.64 -> 2.51-2.54
+        if (g20 <= max_persistent_wgs() && g20 > g24 && cus - g20 >= want)
+            ok = launch_bwd_persistent5<5>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);         // 240 workgroups
+        else if (cus - g24 >= want || g28 >= g24)
+            ok = launch_bwd_persistent5<6>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);         // 204
+        else
+            ok = launch_bwd_persistent5<7>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);         // 174
     }
-    else if (use4 && ngi_ok && parts == 3) ok = DS2_BWD4_GO(6);
+    else if (use4 && ngi_ok && parts == 3)           // (three parts of more than one quad: the counted protocol)
+        ok = launch_bwd_persistent4<6, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);
     else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);

@@ -323,7 +323,7 @@ def recurrence_floor(bsz, t, hid, dev, spare_below):
     hout = torch.zeros(2, t, bsz, hid, device=dev)
     d_out = 0.01 * torch.randn(t, bsz, hid, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    saved = {k: os.environ.get(k) for k in ('DS2_GRU_DBG', 'DS2_GRU_BWD_BCAST')}
+    saved = {k: os.environ.get(k) for k in ('DS2_GRU_DBG',)}
 
     def timed(which, bits, spare=0):
         os.environ['DS2_GRU_DBG'] = str(bits)
@@ -349,7 +349,6 @@ def recurrence_floor(bsz, t, hid, dev, spare_below):
 
     out = {}
     try:
-        os.environ['DS2_GRU_BWD_BCAST'] = '1'          # (the top layer's 20-unit form in the same deal as the forms below)
         for name, which, spare in (('fwd', 'fwd', 0), ('bwd_top_layer_form', 'bwd', 0), ('bwd_lower_layers_form', 'bwd', spare_below)):
             full, skel, mat, hand = (timed(which, b, spare) for b in (0, 2 + 8192, 2048 + 8192, 4096 + 8192))
             if None in (full, skel, mat, hand):
@@ -366,8 +365,7 @@ def recurrence_floor(bsz, t, hid, dev, spare_below):
                    'ablation bits: 2 skeleton only, 2048 no validation = matrix + skeleton, 4096 no MFMAs = hand-off + '
                    'skeleton, each with 8192 = no saved-activation prefetch, whose HBM latency a full step never waits for but a '
                    'shortened one would); hand-off and matrix both contain the hand-off loads\' own round trip; floor = max(hand-off, matrix) + skeleton, because the shipped kernels multiply a fragment as '
-                   'soon as it has landed; achieved_same_build = the unablated launch of the same library (the 20-unit '
-                   'backward form is timed in the broadcast deal here; the release library runs it in the 16-k-blocks deal)')
+                   'soon as it has landed; achieved_same_build = the unablated launch of the same library)')
     return out
 
 
@@ -890,8 +888,8 @@ def main():
                                    'of the CUs it occupies, and the gate / reduction skeleton (DESIGN.md section 6).  achieved / '
                                    'peak / frac price the launch against the fp32-input MFMA roof (the contract\'s yardstick); '
                                    'floor_us_per_step is what the latency model allows',
-                     'kernel': 'the backward recurrence launch: gru_bwd_persistent5_kernel<5, 7> under the layers below the top '
-                               'one, gru_bwd_persistent4_kernel<5, 5, 2, 3> under the top layer (one launch = all T=%d steps of a '
+                     'kernel': 'the backward recurrence launch: gru_bwd_persistent5_kernel<5, 7> (28 units per workgroup) under the '
+                               'layers below the top one, <5, 5> (20 units) under the top layer (one launch = all T=%d steps of a '
                                'BiGRU layer, both directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
