@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/final_r05; rm -rf $OUT; mkdir -p $OUT
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 WHICH=fwd python3 tools/gru_wave_timing.py > $OUT/wave_timing_fwd.txt 2>&1
-( echo "=== DS2_GRU_BWD_BCAST=0 (16-k-blocks deal, 24 units)"; DS2_GRU_BWD_BCAST=0 WHICH=bwd python3 tools/gru_wave_timing.py; echo "=== DS2_GRU_BWD_BCAST=1 (broadcast deal, 24 units)"; DS2_GRU_BWD_BCAST=1 WHICH=bwd python3 tools/gru_wave_timing.py ) > $OUT/wave_timing_bwd_old_new.txt 2>&1
+WHICH=bwd python3 tools/gru_wave_timing.py > $OUT/wave_timing_bwd.txt 2>&1
 soak() { # name, args
   python3 bench.py --no-extras --no-cpu-baseline "${@:2}" > $OUT/soak_$1.json 2> $OUT/soak_$1.err
   python3 - "$1" "$OUT/soak_$1.json" <<'P'
