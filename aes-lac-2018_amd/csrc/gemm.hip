@@ -743,7 +743,14 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
         const unsigned long long abytes = 4ull * (AK ? (unsigned long long)(M - 1) * lda + K : (unsigned long long)(K - 1) * lda + M);
         const unsigned long long bbytes = 4ull * (BKc ? (unsigned long long)(N - 1) * ldb + K : (unsigned long long)(K - 1) * ldb + N);
         if (abytes >= 0x7FFFFFF0ull || bbytes >= 0x7FFFFFF0ull) return -1;
-        // (stream-K runs for a partial last round of tiles, as gemm_f32_v2_kernel has them, were built and measured: gi at
+        // (round 5, built, measured and removed: the same loop on a 256 x 128 tile with EIGHT waves (4 x 2, 64 x 64 outputs each) and
+    // one workgroup per CU -- global loads, split arithmetic and LDS stores per MFMA x 0.75, LDS operand reads per MFMA
+    // unchanged; identical results.  us, 128 x 128 -> 256 x 128: 4096^3 NT / NN / TN 748 / 780 / 825 -> 714 / 740 / 780 (+5 %);
+    // 47744 x 4800 x 800 (B = 64) 1953 -> 1903, 13000 x 4800 x 800 (B = 32) 561 -> 543 (+3 %); 4050 x 4800 x 800 (B = 10)
+    // 179 -> 198 (-10 %: 608 tiles on 256 single-workgroup CUs, nothing fills the last round's bubbles).  3 % of the GEMMs at
+    // B = 32 / 64 did not pay for a second kernel family; what is left in the loop is the LDS operand reads and the per-slab
+    // barrier, i.e. a larger PER-WAVE tile: one wave per SIMD and software-pipelined fragment reads)
+    // (stream-K runs for a partial last round of tiles, as gemm_f32_v2_kernel has them, were built and measured: gi at
         // B = 10, 1292 tiles on 512 slots, 209 -> 204 us, 4096 x 4736 x 800 180 -> 189 us -- these kernels run against the
         // chip's power limit, idle slots give their share back as clock; not kept)
         dim3 grid(tm * tn, nsplit), block(256);
