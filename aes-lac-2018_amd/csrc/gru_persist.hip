@@ -1722,7 +1722,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent4_kernel(float* __
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// Backward recurrence, the BROADCAST deal (round 5; B = 9 .. 12: three batch parts of one quad, speculative hand-off).
+// Backward recurrence, the BROADCAST deal (round 5; B = 5 .. 12: two or three batch parts of one quad, speculative hand-off).
 //
 // gru_bwd_persistent4_kernel gives every one of an instruction's 16 blocks a different k of the SAME 4 units, so each of a
 // wave's NRG accumulators holds 16 partial sums per output: 2 DPP adds per value fold them inside the lane rows -- 40 / 48 /
@@ -1748,15 +1748,15 @@ __device__ __forceinline__ float dpp_row_ror_add(float v) {   // v + (the value 
     const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, true);
     return v + __int_as_float(t);
 }
-template <int NGI, int NRG>
+template <int NGI, int NRG, int NPART = 3>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent5_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        const float* __restrict__ hout,
                                                                        const float* __restrict__ d_out,
                                                                        const float* __restrict__ w_hh_t,
                                                                        SyncWs* __restrict__ sync, float* __restrict__ ring,
                                                                        int T, int B, int H, int dbg, int spec) {
-    static_assert(NRG >= 5 && NRG <= 7, "broadcast deal: 20, 24 or 28 units per workgroup");
-    constexpr int NPART = 3, UNITS = 4 * NRG;
+    static_assert(NRG >= 4 && NRG <= 7 && NPART >= 2 && NPART <= 3, "broadcast deal: 16 .. 28 units per workgroup, 2 or 3 batch parts");
+    constexpr int UNITS = 4 * NRG;
     constexpr bool HASB = NRG >= 6, HASC = (NRG & 1) != 0;
     constexpr int NSLOT = 4, CAHEAD = 2, SIGW = NWP - 1;
     // [value = (row group, unit 4, batch row 4)][RED5_PITCH: 32 partials = (wave, lane row), rotated by 4 ((unit >> 1) + 2 rg)
@@ -3021,22 +3021,22 @@ bool launch_bwd_persistent4(float* G, float* ghn, const float* hout, const float
 }
 
 // the broadcast deal (gru_bwd_persistent5_kernel): three batch parts of one quad each, speculative hand-off
-template <int NRG>
+template <int NRG, int NPART = 3>
 bool launch_bwd_persistent5(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                             SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
     const int opts[] = {1, 2, 3, 5};
     const int ngi = pick_kbw(ds2_cdiv(ds2_cdiv(3 * H, 64), NWP), opts, 4);
-    dim3 grid(ds2_cdiv(H, 4 * NRG), 2, 3), block(NWP * 64);
+    dim3 grid(ds2_cdiv(H, 4 * NRG), 2, NPART), block(NWP * 64);
     // (first-attempt delay and adaptation policy of THIS kernel: DS2_GRU_BWD5_SPEC = "delay,inc,log2clean" for A/B runs)
     // (measured at B = 10, us per step, (14, 1, 2) -> (10, 1, 4): 28 units 2.95 -> 2.86, 24 units 2.74 -> 2.65; 20 units
     // 2.67-2.69 -> 2.54, and 2.51 with (10, 1, 5) -- with that the broadcast deal beats the 16-k-blocks deal's 2.61-2.64 there too)
-    int d = 10, inc = 1, l2c = NRG == 5 ? 5 : 4;
+    int d = NRG == 4 ? 8 : 10, inc = 1, l2c = NRG <= 5 ? 5 : 4;
     if (const char* e = getenv("DS2_GRU_BWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
     const int spec = spec_timing(1, d, inc, l2c);
 #define DS2_BWD5_CASE(K)                                                                                         \
     case K:                                                                                                      \
-        if (!grid_is_coresident(&gru_bwd_persistent5_kernel<K, NRG>, grid, 0)) return false;                     \
-        hipLaunchKernelGGL((gru_bwd_persistent5_kernel<K, NRG>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, sync, ring, \
+        if (!grid_is_coresident(&gru_bwd_persistent5_kernel<K, NRG, NPART>, grid, 0)) return false;              \
+        hipLaunchKernelGGL((gru_bwd_persistent5_kernel<K, NRG, NPART>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, sync, ring, \
                            T, B, H, dbg, spec);                                                                  \
         return true;
     switch (ngi) {
@@ -3326,6 +3326,11 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
     }
     else if (use4 && ngi_ok && parts == 3)           // (three parts of more than one quad: the counted protocol)
         ok = launch_bwd_persistent4<6, 0>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else if (use4 && ngi_ok && parts == 2 && proto != 0 && ds2_cdiv(B, 2) <= 4)
+        // B = 5 .. 8: 16 units and half the batch per workgroup in the broadcast deal (set A only: no fold at all).  us per
+        // step against the 16-k-blocks deal (gru_bwd_persistent4_kernel<5, 4, 2>), B = 8 / 6 / 5: 2.34 / 2.30 / 2.30 -> 2.20 /
+        // 2.15 / 2.11 -- with round 2's hand-off timing the two were level (2.33-2.37 against 2.34-2.35 at B = 8)
+        ok = launch_bwd_persistent5<4, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);
     else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
