@@ -41,6 +41,9 @@ struct GatherGeom {
     int row_len, rows_per_b;
     int a_base, a_b_stride, a_row_stride;
     int o_base, o_b_stride, o_row_stride, o_col_stride;
+    int frows;                               // > 0 (data gradient, K not split over workgroups): filter rows of this parity; a
+                                             // workgroup multiplies only the tap groups whose filter rows reach an output row
+                                             // from one of ITS input rows
 };
 
 template <int NPROD, int NT>
@@ -58,8 +61,25 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
     const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
     constexpr int WG_M = 128 * NT;                                       // positions per workgroup: 4 waves x NT row tiles of 32
     const int m0 = tile * WG_M;
-    const int nstep_all = g.npairs * g.ngroups;
-    const int sbeg = blockIdx.y * steps_per_split, send = min(nstep_all, sbeg + steps_per_split);
+    // Data gradient: input row f' of a parity takes filter row kh' through output row f' - kh', which exists for
+    // 0 <= f' - kh' <= 20 -- the 10 top and 10 bottom input rows of a parity use 1 .. 10 of its 11 / 10 filter rows, every other
+    // tap multiplies the zero border (31 % of the steps of a launch).  A workgroup's positions lie in one or two adjacent rows:
+    // it walks the tap groups [glo, ghi) of the filter-row PAIRS its rows need (three groups per pair, see tap_slot).
+    int glo = 0, ghi = g.ngroups;
+    if (g.frows > 0) {
+        const int p0 = min(m0, g.M - 1), p1 = min(m0 + WG_M, g.M) - 1;
+        const int ri0 = p0 / g.row_len, ri1 = p1 / g.row_len;
+        const int r0 = ri0 % g.rows_per_b, r1 = ri1 % g.rows_per_b;
+        if (ri1 - ri0 <= 1 && r1 >= r0) {                 // (not across two batch elements: there the whole range)
+            const int lo = max(0, r0 - 20), hi = min(g.frows - 1, r1);
+            glo = 3 * (lo >> 1);
+            ghi = min(g.ngroups, 3 * (hi >> 1) + 3);
+        }
+    }
+    const int ngr = ghi - glo;
+    const int nstep_all = g.npairs * ngr;                 // steps of this workgroup
+    const int sbeg = g.frows > 0 ? 0 : blockIdx.y * steps_per_split;
+    const int send = g.frows > 0 ? nstep_all : min(nstep_all, sbeg + steps_per_split);
     auto decode = [&](int p, int& va, int& vo) {
         va = G_OOB;
         vo = -1;
@@ -94,21 +114,22 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
     // multiplied.  (The input does not fit one XCD's L2 next to its neighbours' share: a third of the L2 requests go on to
     // the Infinity Cache, and with one set in flight the waves spent half their cycles waiting for them.)
     constexpr int NSET = 4;
-    int cp = sbeg / g.ngroups, gq = sbeg - cp * g.ngroups;               // (channel pair, tap group) of the next table read
+    int cp = sbeg / ngr, gq = glo + sbeg - cp * ngr;                     // (channel pair, tap group) of the next table read
     f32x4 ra[NSET][NT][2];                                               // [set][row tile][run of 4 taps]
     uint4 rw[NSET][3];
-    int so[2];
-    auto read_tab = [&](int (&o)[2]) {
+    int so[3];                                                           // two run offsets and the step's place in the filter image
+    auto read_tab = [&](int (&o)[3]) {
         const int* tab = tap_off + gq * 2;
         const int pbase = cp * g.pair_stride;
         o[0] = (pbase + tab[0]) * 4;                                     // wave-uniform: scalar loads
         o[1] = (pbase + tab[1]) * 4;
-        if (++gq == g.ngroups) {
-            gq = 0;
+        o[2] = (cp * g.ngroups + gq) * 3 * 1024;
+        if (++gq == ghi) {
+            gq = glo;
             ++cp;
         }
     };
-    auto issue = [&](int s, f32x4 (&a)[NT][2], uint4 (&w)[3], const int (&o)[2]) {
+    auto issue = [&](f32x4 (&a)[NT][2], uint4 (&w)[3], const int (&o)[3]) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -116,20 +137,20 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
                 a[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, va[i], o[h], 0));
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            w[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, vw, (s * 3 + q) * 1024, 0));
+            w[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsw, vw, o[2] + q * 1024, 0));
     };
     // prologue: steps sbeg .. sbeg + NSET - 2 in flight, the table entry of step sbeg + NSET - 1 read
     read_tab(so);
-    issue(sbeg, ra[0], rw[0], so);
+    issue(ra[0], rw[0], so);
     read_tab(so);
-    issue(sbeg + 1, ra[1], rw[1], so);
+    issue(ra[1], rw[1], so);
     read_tab(so);
-    issue(sbeg + 2, ra[2], rw[2], so);
+    issue(ra[2], rw[2], so);
     read_tab(so);                                                        // for step sbeg + 3, issued by the loop's first step
-    auto step = [&](int s, auto PAR) {
+    auto step = [&](int, auto PAR) {
         constexpr int cur = decltype(PAR)::value;                        // (s - sbeg) mod NSET
         constexpr int nxt = (cur + NSET - 1) % NSET;
-        issue(s + NSET - 1, ra[nxt], rw[nxt], so);                       // (past the end: zeros or values nobody uses; the
+        issue(ra[nxt], rw[nxt], so);                                     // (past the end: zeros or values nobody uses; the
         read_tab(so);                                                    // table and the filter image are padded)
         bf16x8 a[NT][3], b[3];
 #pragma unroll
@@ -347,6 +368,7 @@ int ds2_conv2_fwd_split(const float* in, const float* weight, const float* bias,
     g.o_b_stride = 32 * 21 * tout;
     g.o_row_stride = tout;
     g.o_col_stride = 21 * tout;
+    g.frows = 0;
     const int nstep = NP * NG;
     const unsigned int w_bytes = (unsigned int)((NP * NG + SPARE) * 3 * 32 * 16 * 2);
     launch_gather(mode, in, (unsigned int)a_bytes, tap_off, Wp, w_bytes, bias, out, o_elems, g, nstep, nullptr, st);
@@ -408,6 +430,9 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
         g.o_b_stride = 32 * 61 * t1;
         g.o_row_stride = 2 * t1;
         g.o_col_stride = 61 * t1;
+        // (DS2_CONV_DGRAD_ROWS = 0: every workgroup walks all tap groups, as until round 5 -- A/B timing)
+        static const bool rows_off = getenv("DS2_CONV_DGRAD_ROWS") && getenv("DS2_CONV_DGRAD_ROWS")[0] == '0';
+        g.frows = (!rows_off && plan_gather(g.M, 16 * ng, true).nsplit == 1) ? nrows : 0;
         const unsigned int w_bytes = (unsigned int)((16 * ng + SPARE) * 3 * 32 * 16 * 2);
         launch_gather(mode, dyp, (unsigned int)a_bytes, tab + 512 * par, Wp[par], w_bytes, nullptr, d_in, o_elems, g, 16 * ng,
                       &zeroed, st);
