@@ -51,14 +51,31 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
                                                               const int* __restrict__ tap_off,
                                                               const unsigned int* __restrict__ Wp, unsigned int w_bytes,
                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                              GatherGeom g, int steps_per_split, int use_atomic) {
+                                                              GatherGeom g, int steps_per_split, int use_atomic,
+                                                              int tiles0, int tiles1, const int* __restrict__ tap_off1,
+                                                              const unsigned int* __restrict__ Wp1, unsigned int w_bytes1,
+                                                              GatherGeom g1) {
     __shared__ int sh_o[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; give every XCD a contiguous run of positions (its
     // L2 then holds the 21 input rows its neighbouring tiles share)
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, qd = nwg >> 3, rm = nwg & 7;
-    const int tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (blockIdx.x >> 3);
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int n0 = (tiles0 >> 3) + (xcd < (tiles0 & 7) ? 1 : 0);
+    int tile = xcd * (tiles0 >> 3) + min(xcd, tiles0 & 7) + jx;
+    // Two problems in one launch (the data gradient's two input-row parities, tiles0 and tiles1 tiles of positions: one tail
+    // instead of two, and with the row-dependent step counts below twice the workgroups to balance over the chip's 512 slots).
+    // An XCD takes ITS eighth of the first problem's positions, then its eighth of the second's -- the two read the same
+    // rows of A (dealing the concatenated tiles out in eighths put a quarter of A through every L2: T_in = 400 0.211 -> 0.235 ms).
+    if (jx >= n0) {
+        const int n1 = (tiles1 >> 3) + (xcd < (tiles1 & 7) ? 1 : 0);
+        if (jx - n0 >= n1) return;                                       // (the grid is padded to 8 x the fullest XCD's share)
+        tile = xcd * (tiles1 >> 3) + min(xcd, tiles1 & 7) + jx - n0;
+        g = g1;
+        tap_off = tap_off1;
+        Wp = Wp1;
+        w_bytes = w_bytes1;
+    }
     constexpr int WG_M = 128 * NT;                                       // positions per workgroup: 4 waves x NT row tiles of 32
     const int m0 = tile * WG_M;
     // Data gradient: input row f' of a parity takes filter row kh' through output row f' - kh', which exists for
@@ -312,11 +329,19 @@ GatherPlan plan_gather(int M, int nstep, bool may_split) {
 // output once, in front of its first launch, if ANY of its launches splits: the two row-parity launches of the data gradient
 // pick their split separately -- 31 against 30 rows per batch element can put them on either side of a threshold -- and a
 // fill issued by the second one would wipe the rows the first one has written).
+// g1 != nullptr: a second problem on the same A and out in the same launch (both unsplit over K, same positions per wave)
 void launch_gather(int mode, const float* A, unsigned int a_bytes, const int* tab, const unsigned int* Wp, unsigned int w_bytes,
                    const float* bias, float* out, unsigned long long o_elems, const GatherGeom& g, int nstep, bool* zeroed,
-                   hipStream_t st) {
-    const GatherPlan pl = plan_gather(g.M, nstep, zeroed != nullptr);
-    const int nt = pl.nt, tiles = pl.tiles, per = pl.per, nsplit = pl.nsplit;
+                   hipStream_t st, const GatherGeom* g1 = nullptr, const int* tab1 = nullptr, const unsigned int* Wp1 = nullptr,
+                   unsigned int w_bytes1 = 0, int force_nt = 0) {
+    GatherPlan pl = plan_gather(g.M, nstep, zeroed != nullptr);
+    if (force_nt > 0) {
+        pl.nt = force_nt;
+        pl.tiles = ds2_cdiv(g.M, 128 * pl.nt);
+    }
+    const int nt = pl.nt, tiles0 = pl.tiles, per = pl.per, nsplit = pl.nsplit;
+    const int tiles1 = g1 ? ds2_cdiv(g1->M, 128 * nt) : 0;
+    const int tiles = g1 ? 8 * ((tiles0 >> 3) + (tiles1 >> 3) + ((tiles0 & 7) ? 1 : 0) + ((tiles1 & 7) ? 1 : 0)) : tiles0;
     if (nsplit > 1 && !*zeroed) {       // (not reached from ds2_conv2_dgrad_split, which fills up front; kept for other callers)
         (void)hipMemsetAsync(out, 0, o_elems * sizeof(float), st);
         *zeroed = true;
@@ -325,7 +350,8 @@ void launch_gather(int mode, const float* A, unsigned int a_bytes, const int* ta
     dim3 grid(tiles, nsplit), block(256);
     const int at = nsplit > 1 ? 1 : 0;
 #define DS2_GATHER_GO(P_, N_)                                                                                            \
-    hipLaunchKernelGGL((conv2_gather_kernel<P_, N_>), grid, block, 0, st, A, a_bytes, tab, Wp, w_bytes, bias, out, g, per, at)
+    hipLaunchKernelGGL((conv2_gather_kernel<P_, N_>), grid, block, 0, st, A, a_bytes, tab, Wp, w_bytes, bias, out, g, per, at, \
+                       tiles0, tiles1, tab1, Wp1, w_bytes1, g1 ? *g1 : g)
     if (mode == 6 && nt == 2) DS2_GATHER_GO(6, 2);
     else if (mode == 6) DS2_GATHER_GO(6, 1);
     else if (nt == 2) DS2_GATHER_GO(9, 2);
@@ -410,12 +436,15 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
     for (int par = 0; par < 2; ++par)
         if (plan_gather(B * (par == 0 ? 31 : 30) * t1, 16 * tap_groups(par == 0 ? 11 : 10), true).nsplit > 1) zeroed = true;
     if (zeroed) (void)hipMemsetAsync(d_in, 0, o_elems * sizeof(float), st);
+    GatherGeom gg[2];
+    unsigned int wb[2];
+    GatherPlan pp[2];
     for (int par = 0; par < 2; ++par) {
         const int nrows = par == 0 ? 11 : 10, ng = tap_groups(nrows), RH = par == 0 ? 31 : 30;
         const int prep = (16 * ng + SPARE) * 32 * 2 * 4;
         hipLaunchKernelGGL(conv2_split_prepare_kernel, dim3(ds2_cdiv(prep, 256)), dim3(256), 0, st, weight, 1 + par, nrows, TP,
                            SPARE, tab + 512 * par, Wp[par]);
-        GatherGeom g;
+        GatherGeom& g = gg[par];
         g.M = B * RH * t1;
         g.ngroups = ng;
         g.npairs = 16;
@@ -432,10 +461,19 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
         g.o_col_stride = 61 * t1;
         // (DS2_CONV_DGRAD_ROWS = 0: every workgroup walks all tap groups, as until round 5 -- A/B timing)
         static const bool rows_off = getenv("DS2_CONV_DGRAD_ROWS") && getenv("DS2_CONV_DGRAD_ROWS")[0] == '0';
-        g.frows = (!rows_off && plan_gather(g.M, 16 * ng, true).nsplit == 1) ? nrows : 0;
-        const unsigned int w_bytes = (unsigned int)((16 * ng + SPARE) * 3 * 32 * 16 * 2);
-        launch_gather(mode, dyp, (unsigned int)a_bytes, tab + 512 * par, Wp[par], w_bytes, nullptr, d_in, o_elems, g, 16 * ng,
-                      &zeroed, st);
+        pp[par] = plan_gather(g.M, 16 * ng, true);
+        g.frows = (!rows_off && pp[par].nsplit == 1) ? nrows : 0;
+        wb[par] = (unsigned int)((16 * ng + SPARE) * 3 * 32 * 16 * 2);
+    }
+    // both parities in ONE launch when neither splits K (DS2_CONV_DGRAD_MERGE = 0: two launches, as until round 5 -- A/B timing)
+    static const bool merge_off = getenv("DS2_CONV_DGRAD_MERGE") && getenv("DS2_CONV_DGRAD_MERGE")[0] == '0';
+    if (!merge_off && pp[0].nsplit == 1 && pp[1].nsplit == 1) {
+        launch_gather(mode, dyp, (unsigned int)a_bytes, tab, Wp[0], wb[0], nullptr, d_in, o_elems, gg[0], 16 * gg[0].ngroups,
+                      &zeroed, st, &gg[1], tab + 512, Wp[1], wb[1], pp[0].nt);
+    } else {
+        for (int par = 0; par < 2; ++par)
+            launch_gather(mode, dyp, (unsigned int)a_bytes, tab + 512 * par, Wp[par], wb[par], nullptr, d_in, o_elems, gg[par],
+                          16 * gg[par].ngroups, &zeroed, st);
     }
     return 0;
 }
