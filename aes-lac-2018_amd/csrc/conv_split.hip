@@ -80,14 +80,15 @@ __global__ __launch_bounds__(256, 2) void conv2_gather_kernel(const float* __res
     const int m0 = tile * WG_M;
     // Data gradient: input row f' of a parity takes filter row kh' through output row f' - kh', which exists for
     // 0 <= f' - kh' <= 20 -- the 10 top and 10 bottom input rows of a parity use 1 .. 10 of its 11 / 10 filter rows, every other
-    // tap multiplies the zero border (31 % of the steps of a launch).  A workgroup's positions lie in one or two adjacent rows:
-    // it walks the tap groups [glo, ghi) of the filter-row PAIRS its rows need (three groups per pair, see tap_slot).
+    // tap multiplies the zero border (31 % of the steps of a launch).  A workgroup's positions lie in a few adjacent rows (one or
+    // two at the bench shapes): it walks the tap groups [glo, ghi) of the filter-row PAIRS those rows need (three groups per
+    // pair, see tap_slot).
     int glo = 0, ghi = g.ngroups;
     if (g.frows > 0) {
         const int p0 = min(m0, g.M - 1), p1 = min(m0 + WG_M, g.M) - 1;
         const int ri0 = p0 / g.row_len, ri1 = p1 / g.row_len;
         const int r0 = ri0 % g.rows_per_b, r1 = ri1 % g.rows_per_b;
-        if (ri1 - ri0 <= 1 && r1 >= r0) {                 // (not across two batch elements: there the whole range)
+        if (ri0 / g.rows_per_b == ri1 / g.rows_per_b) {   // rows r0 .. r1 of ONE batch element (across two: the whole range)
             const int lo = max(0, r0 - 20), hi = min(g.frows - 1, r1);
             glo = 3 * (lo >> 1);
             ghi = min(g.ngroups, 3 * (hi >> 1) + 3);
@@ -459,14 +460,17 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
         g.o_b_stride = 32 * 61 * t1;
         g.o_row_stride = 2 * t1;
         g.o_col_stride = 61 * t1;
-        // (DS2_CONV_DGRAD_ROWS = 0: every workgroup walks all tap groups, as until round 5 -- A/B timing)
-        static const bool rows_off = getenv("DS2_CONV_DGRAD_ROWS") && getenv("DS2_CONV_DGRAD_ROWS")[0] == '0';
+        // (DS2_CONV_DGRAD_ROWS = 0: every workgroup walks all tap groups, as until round 5 -- A/B timing and the test that holds
+        // the two walks to the same bits; read per call)
+        const char* rows_env = getenv("DS2_CONV_DGRAD_ROWS");
+        const bool rows_off = rows_env && rows_env[0] == '0';
         pp[par] = plan_gather(g.M, 16 * ng, true);
         g.frows = (!rows_off && pp[par].nsplit == 1) ? nrows : 0;
         wb[par] = (unsigned int)((16 * ng + SPARE) * 3 * 32 * 16 * 2);
     }
     // both parities in ONE launch when neither splits K (DS2_CONV_DGRAD_MERGE = 0: two launches, as until round 5 -- A/B timing)
-    static const bool merge_off = getenv("DS2_CONV_DGRAD_MERGE") && getenv("DS2_CONV_DGRAD_MERGE")[0] == '0';
+    const char* merge_env = getenv("DS2_CONV_DGRAD_MERGE");
+    const bool merge_off = merge_env && merge_env[0] == '0';
     if (!merge_off && pp[0].nsplit == 1 && pp[1].nsplit == 1) {
         launch_gather(mode, dyp, (unsigned int)a_bytes, tab, Wp[0], wb[0], nullptr, d_in, o_elems, gg[0], 16 * gg[0].ngroups,
                       &zeroed, st, &gg[1], tab + 512, Wp[1], wb[1], pp[0].nt);

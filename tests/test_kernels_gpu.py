@@ -263,6 +263,30 @@ def test_conv_fwd_bwd(ops, monkeypatch, which, bsz, t_in, form):
         np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), atol=2e-5)
 
 
+@pytest.mark.parametrize('bsz,t1', [(12, 90), (10, 415), (3, 500), (1, 1060)])
+def test_conv2_dgrad_row_walk_and_single_launch_hold_the_plain_walks_bits(ops, monkeypatch, bsz, t1):
+    """Round 5: a workgroup of the gather data gradient walks only the tap groups whose filter rows reach an output row from
+    its input rows, and both input-row parities run in one launch (csrc/conv_split.hip).  What is skipped are products with
+    the zero border, so the result must equal the plain walk's (every group, two launches) BIT FOR BIT -- at shapes where
+    the launch does not split K (12 x 90: a tile of 128 positions spans two or three input rows; 10 x 415: the bench's mean
+    bin; 1 x 1060: one parity splits K, so the two-launch path with one row-walking launch) -- and F.conv2d's gradient."""
+    monkeypatch.setenv('DS2_CONV_SPLIT_DGRAD', '1')
+    rng = np.random.default_rng(bsz * 1000 + t1)
+    w = torch.from_numpy((rng.standard_normal((32, 32, 21, 11)) / np.sqrt(32 * 21 * 11)).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((bsz, 32, 21, t1 - 10)).astype(np.float32))
+    got = ops.conv2_dgrad(dy.to(DEV), w.to(DEV), t1).cpu()
+    monkeypatch.setenv('DS2_CONV_DGRAD_ROWS', '0')
+    monkeypatch.setenv('DS2_CONV_DGRAD_MERGE', '0')
+    plain = ops.conv2_dgrad(dy.to(DEV), w.to(DEV), t1).cpu()
+    if (bsz, t1) != (1, 1060):                       # (float atomics where K is split: not bitwise reproducible)
+        assert torch.equal(got, plain)
+    else:
+        np.testing.assert_allclose(got.numpy(), plain.numpy(), atol=2e-6)
+    x = torch.zeros(bsz, 32, 61, t1, requires_grad=True)
+    F.conv2d(x, w, None, stride=(2, 1)).backward(dy)
+    np.testing.assert_allclose(got.numpy(), x.grad.numpy(), atol=2e-5)
+
+
 def test_conv2_dgrad_workspace_contract(ops, monkeypatch):
     """ds2_conv2_dgrad takes the SIZE of its workspace (ABI revision 400): with the filter-layout size only it must run the
     direct kernel -- not write its gather form's zero-bordered copy of d_out past the end -- and with less than that return
