@@ -750,6 +750,12 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
     // 179 -> 198 (-10 %: 608 tiles on 256 single-workgroup CUs, nothing fills the last round's bubbles).  3 % of the GEMMs at
     // B = 32 / 64 did not pay for a second kernel family; what is left in the loop is the LDS operand reads and the per-slab
     // barrier, i.e. a larger PER-WAVE tile: one wave per SIMD and software-pipelined fragment reads)
+    // (round 5, measured and not kept: s_setprio 1 / 3 around a slab's MFMA block, 0 in front of the barrier -- of the two
+    // workgroups a CU holds, the one that can feed the matrix pipe issues first.  Stand-alone, same box, us: dX (NN) 4240 x 800
+    // x 4800 208 -> 201, dW_ih (TN) 218 -> 209, at 12500 rows 624 -> 607 / 582 -> 558, grouped dW_hh 198 -> 189, the input
+    // projection (NT) and 4096^3 within 1 %; the whole step, three alternating pairs of 60 steps: B = 10 14.31 / 14.36 / 14.52
+    // without against 14.87 / 14.51 / 14.27 ms with, B = 32 31.05 / 31.31 against 31.31 / 30.91, B = 64 x 15 s 99.3 against
+    // 100.2 -- nothing: inside the step these GEMMs share the chip with other kernels, not with a second workgroup of their own)
     // (stream-K runs for a partial last round of tiles, as gemm_f32_v2_kernel has them, were built and measured: gi at
         // B = 10, 1292 tiles on 512 slots, 209 -> 204 us, 4096 x 4736 x 800 180 -> 189 us -- these kernels run against the
         // chip's power limit, idle slots give their share back as clock; not kept)

@@ -2,6 +2,8 @@
 import os, sys
 sys.path.insert(0, 'aes-lac-2018_amd'); sys.path.insert(0, '.')
 import torch, numpy as np
+from ds2hip import lib
+if os.environ.get('DS2_LIB_VARIANT'): lib.LIB_PATH = os.path.join(os.path.dirname(lib.LIB_PATH), 'libds2hip_%s.so' % os.environ['DS2_LIB_VARIANT'])
 from ds2hip import ops
 rows = int(os.environ.get('ROWS', '4240'))
 shapes = [('warm NT', 0, 1, 4096, 4096, 4096, 1), ('gi   NT', 0, 1, rows, 4800, 800, 0), ('gi0  NT', 0, 1, rows, 4800, 672, 0),
