@@ -187,6 +187,7 @@ class Trainer(object):
             bns = self._bn_modules = [m for m in model.modules() if hasattr(m, 'num_batches_tracked')]
         if not model.training or not all(m.training for m in bns):
             model.train()
+        model._ensure_flat()        # the re-pack is lazy: run its (cheap) check NOW, so that a swap just before this call is seen
         if model._flat_p is not self._bound_flat:
             # (a sub-module or parameter was replaced after this Trainer was built -- fine-tuning surgery belongs BEFORE the
             # optimizer and the trainer are created, as train.py does it: the flat spans of the fused update, the momentum

@@ -101,7 +101,9 @@ def gpu_numa_nodes(sysfs='/', environ=None):
         bdf = '%04x:%02x:%02x.%x' % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7)
         node = _read(os.path.join(sysfs, 'sys/bus/pci/devices', bdf, 'numa_node'))
         gpus.append(int(node) if node is not None and node.strip().lstrip('-').isdigit() else None)
-    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):     # applied in this order by the stack
+    # ROCR's filter first (the runtime below HIP), then ONE HIP-level filter: on ROCm HIP_VISIBLE_DEVICES and
+    # CUDA_VISIBLE_DEVICES are two names of the same list, not a composition -- HIP's wins when both are set
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES' if env.get('HIP_VISIBLE_DEVICES') else 'CUDA_VISIBLE_DEVICES'):
         v = env.get(var)
         if v:
             try:
@@ -129,12 +131,19 @@ def numa_cpu_plan(local_rank, local_world, sysfs='/', environ=None, current=None
     peers = [r for r in range(min(local_world, len(nodes))) if nodes[r] == mine]
     if local_rank not in peers or not cpus:
         return None
-    order = sorted(cpus)
+    # split by PHYSICAL core: the SMT siblings of a core (thread_siblings_list) go to the same rank -- an even split of the
+    # sorted logical ids can hand two ranks the two hardware threads of the same cores
+    cores = {}
+    for c in sorted(cpus):
+        sib = _read(os.path.join(sysfs, 'sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c))
+        key = min(_parse_cpulist(sib)) if sib and sib.strip() else c
+        cores.setdefault(key, []).append(c)
+    order = [cores[k] for k in sorted(cores)]
     share = len(order) // len(peers)
     if share < 2:
-        return set(order)                                     # fewer than two CPUs per rank: share the node
+        return set(cpus)                                      # fewer than two cores per rank: share the node
     k = peers.index(local_rank)
-    return set(order[k * share:(k + 1) * share])
+    return {c for core in order[k * share:(k + 1) * share] for c in core}
 
 
 def pin_to_gpu_numa_node(local_rank, local_world):

@@ -21,6 +21,6 @@ void ds2_set_error(const char* fmt, ...) {
 extern "C" const char* ds2_last_error(void) { return g_err; }
 // = DS2_ABI_VERSION of include/ds2hip.h (the header is C documentation of the ABI and is not included by the sources; the
 // CPU test suite compares the two numbers)
-extern "C" int ds2_version(void) { return 401; }
+extern "C" int ds2_version(void) { return 402; }
 // the digest of the sources this binary was built from (csrc/build.py: source_id()); ds2hip/lib.py compares it with the tree
 extern "C" const char* ds2_build_id(void) { return DS2_BUILD_ID; }

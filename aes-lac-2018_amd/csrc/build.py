@@ -7,9 +7,9 @@ Each .hip file is compiled to an object (cached by mtime) and linked into
 aes-lac-2018_amd/ds2hip/libds2hip.so.  The .so is git-ignored but travels to the GPU box.
 
 A second library, libds2hip_faultinject.so, differs in ONE object: gru_persist.hip compiled with
--DDS2_FAULT_INJECT=1, which lets DS2_GRU_DBG=64 drop a workgroup's arrival.  Only
-tests/fault_inject_worker.py loads it (the bounded-spin / sticky-flag / fall-back test); the release library
-never reads that variable.
+-DDS2_FAULT_INJECT=1, which lets DS2_GRU_DBG=64 drop a workgroup's arrival (and the other ablation bits take effect).
+tests/fault_inject_worker.py loads it (the bounded-spin / sticky-flag / fall-back test), and so does bench.py's
+recurrence-floor leg (ablated launches of the shipped kernels' own source); the release library never reads that variable.
 """
 import os
 import subprocess

@@ -1954,7 +1954,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent5_kernel(float* __
                 const f32x4 ps = p0 + p1;
                 part = (ps[0] + ps[1]) + (ps[2] + ps[3]);
             }
-            part = dpp_row_ror_add<8>(dpp_row_ror_add<4>(part));      // the four gparts of a unit sit 4 lanes apart
+            // the four gparts of a unit sit 4 lanes apart.  ror:8 FIRST: lanes l and l + 8 then hold identical bits, so the ror:4
+            // step gives all four gparts (p0 + p2) + (p1 + p3) to the bit -- each keeps its own dh recurrence and stores a
+            // different gate's output, which must come from ONE trajectory
+            part = dpp_row_ror_add<4>(dpp_row_ror_add<8>(part));
             if (gate_ok) {
                 dh += part + dhz;
                 const float dn_pre = dh * (1.f - z) * (1.f - n * n);

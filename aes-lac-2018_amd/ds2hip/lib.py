@@ -68,7 +68,7 @@ SIGNATURES = {
     'ds2_ctc_beam_search': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
 }
 
-ABI_VERSION = 401            # DS2_ABI_VERSION of include/ds2hip.h: the revision this table (and ops.py) is written against
+ABI_VERSION = 402            # DS2_ABI_VERSION of include/ds2hip.h: the revision this table (and ops.py) is written against
 
 _lib = None
 
@@ -91,11 +91,16 @@ def load():
             raise RuntimeError('libds2hip.so is missing at %s -- run `python aes-lac-2018_amd/csrc/build.py` '
                                '(or __graft_entry__.build()); there is no fallback path' % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
-            fn.restype = res
-            fn.argtypes = args
+        # the revision FIRST, before any other symbol is resolved: a stale binary that lacks a newer entry point must die with
+        # the 'rebuild it' message below, not with a bare AttributeError from the binding loop
+        lib.ds2_version.restype = ctypes.c_int
+        lib.ds2_version.argtypes = []
         have = lib.ds2_version()
+        if have == ABI_VERSION:
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
         if have != ABI_VERSION:
             # signatures change between revisions without a change of symbol name: a stale binary would mis-pass arguments
             raise RuntimeError('%s is ABI revision %d, this binding is written against %d (include/ds2hip.h DS2_ABI_VERSION) '

@@ -587,6 +587,30 @@ def loader_leg(trainer, plan, dev, workers=4):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def self_launch_command(ngpus, argv, port=None):
+    """The command `bench.py --gpus N` (N > 1) runs when no launcher started it: one rank per GPU of this node through
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    port = port or os.environ.get('MASTER_PORT') or '29531'
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ngpus),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(ngpus, argv, runner=None):
+    """Run the ranks as a child process (never an exec: this process must stay alive to return the code), hand the
+    child's stdout -- rank 0's one JSON line -- through unchanged, return the child's exit code."""
+    import subprocess
+    cmd = self_launch_command(ngpus, argv)
+    note('no launcher in the environment: starting %d ranks: %s' % (ngpus, ' '.join(cmd)))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this pool's host driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // ngpus)))
+    proc = (runner or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE)
+    out = proc.stdout.decode() if isinstance(proc.stdout, bytes) else (proc.stdout or '')
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -600,7 +624,22 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary shapes and the loader leg')
     ap.add_argument('--fixed-seconds', type=float, default=0.0,
                     help='profiling aid: every clip this long (e.g. --batch-size 64 --fixed-seconds 15 = the fixed worst case)')
+    ap.add_argument('--protocol', choices=('driver', 'survey'), default='driver',
+                    help="survey = SURVEY.md 8(d)'s literal protocol: 20 warm-up + 100 timed steps (sets --warmup / --steps); "
+                         'the line always carries median / p10 / p90 of the per-step rates')
+    ap.add_argument('--no-floor', action='store_true',
+                    help="skip the recurrence-floor leg (ablated launches of the fault-injection library, which appear in a "
+                         "kernel trace under the product kernels' names)")
+    ap.add_argument('--no-f32-leg', action='store_true', help='skip the leg that repeats the steps on the f32-input GEMM kernels')
     args = ap.parse_args()
+    if args.protocol == 'survey':
+        args.warmup, args.steps = 20, 100
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it (the way the driver runs `--gpus 1`): start the N
+    # ranks ourselves, as a CHILD process -- this process has not touched the GPU and never will -- pass rank 0's one JSON
+    # line through and leave with the child's return code (the reference: train.py:118-124 is started the same way)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly one line, the JSON result: RCCL prints a version banner to the C-level stdout (flushed at
     # exit, i.e. after our line), so fd 1 is pointed at stderr for the run and the result goes to the saved descriptor
@@ -699,7 +738,7 @@ def main():
     from ds2hip import ops as _ops
     gemm_mode = _ops.gemm_split_mode()
     dt_f32 = None
-    if gemm_mode != 0:
+    if gemm_mode != 0 and not args.no_f32_leg:
         _ops.gemm_split_mode(0)
         saved_env = {k: os.environ.get(k) for k in ('DS2_CONV_SPLIT', 'DS2_GRU_P2_BF16')}
         os.environ['DS2_CONV_SPLIT'] = '0'           # (read per call by the library: conv2 forward on the direct kernels,
@@ -808,7 +847,7 @@ def main():
     note('inference leg done')
     roof = gru_pass_roofline(model, bsz, t_mean)
     from codes.model import _BWD_SPARE_CUS
-    floor = recurrence_floor(bsz, t_mean, model._rnn_hidden_size, dev, _BWD_SPARE_CUS)
+    floor = None if args.no_floor else recurrence_floor(bsz, t_mean, model._rnn_hidden_size, dev, _BWD_SPARE_CUS)
     gemm_roof = gemm_roofline(model, t_mean * bsz)
     note('roofline legs done')
     mean_bin = min(range(len(mine)), key=lambda i: abs(out_steps_of(mine[i]) / len(mine[i][0]) - t_mean))
@@ -824,7 +863,7 @@ def main():
     # HBM-side bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc run of the same shape whose
     # summary is committed under profiles/ (PMC collection cannot run inside this process); the file is named below
     traffic, traffic_src, traffic_floor, traffic_alg = None, None, None, None
-    for name in ('r05_traffic.json',):
+    for name in ('r06_traffic.json', 'r05_traffic.json'):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', name)))
             if rec['shape'] == {'T': t_mean, 'B': bsz, 'H': 800}:
@@ -850,6 +889,9 @@ def main():
                    'last_loss': round(float(loss), 4),
                    'protocol': 'value / ms_per_step: a host synchronisation at the end of EVERY step (codes/engine.py:92, SURVEY.md '
                                '8d); frames = valid spectrogram frames 1 + L // 160 of every clip (padding not counted)',
+                   'protocol_name': args.protocol + (' (SURVEY.md 8d: 20 warm-up + 100 timed steps; median / p10 / p90 in '
+                                                     'frames_per_s_per_step_rank0 and ms_per_step_rank0)' if args.protocol == 'survey'
+                                                     else " (the driver's command line: --steps / --warmup as given)"),
                    'padded_frames_per_s': round(pframes / dt, 1),
                    'padding_note': 'a bin is padded to its longest clip (codes/data.py:132-152): B x T_max frames are computed per '
                                    'step, the valid ones are counted',

@@ -39,7 +39,7 @@ const char* ds2_last_error(void);
  * have changed between revisions without a change of symbol name (round 3: an amplitude-scale argument in
  * ds2_pcm16_to_float / ds2_gain_requantize; round 4: ds2_conv2_dgrad takes the size of its workspace), so a binding built
  * against another revision mis-passes arguments.  ds2hip/lib.py refuses to load a library whose number differs. */
-#define DS2_ABI_VERSION 401
+#define DS2_ABI_VERSION 402
 int ds2_version(void);
 /* A digest of the sources the loaded binary was built from (csrc/build.py: source_id(); "unstamped" for a build made without
  * build.py).  The Python binding recomputes it from the tree beside it and refuses a binary built from other sources, so a

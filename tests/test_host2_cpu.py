@@ -2,6 +2,7 @@
 and the data-parallel partition + bucketed all-reduce under a 2-process gloo group."""
 import json
 import os
+import sys
 import wave
 
 import numpy as np
@@ -522,6 +523,65 @@ def test_bench_bin_plan_is_the_reference_partition(world):
         assert np.all(np.diff(e[1]) >= 0) and 1.0 <= e[1][0] and e[1][-1] <= 15.0
 
 
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench, root
+
+
+def test_bench_gpus_n_starts_its_own_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` the way the driver runs `--gpus 1` (no launcher, no WORLD_SIZE): bench.py composes the
+    torch.distributed.run command itself (one rank per GPU, rendezvous on 127.0.0.1: the reference is started the same way,
+    train.py:118-124), runs it as a CHILD (no exec: the box refuses an exec from a process that could have touched the
+    GPU), hands the child's one stdout line through and returns its exit code."""
+    bench, root = _load_bench()
+    cmd = bench.self_launch_command(8, ['--gpus', '8', '--steps', '20', '--warmup', '5'], port=29999)
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '8'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29999'
+    script = cmd.index(os.path.join(root, 'bench.py'))
+    assert cmd[script + 1:] == ['--gpus', '8', '--steps', '20', '--warmup', '5']
+
+    seen = {}
+
+    class Done:
+        stdout = b'{"metric": "stub", "n_gpus": 4}\n'
+        returncode = 7
+
+    def runner(cmd, env=None, stdout=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return Done()
+
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    rc = bench.self_launch(4, ['--gpus', '4'], runner=runner)
+    assert rc == 7                                                       # the child's code is the parent's
+    assert capsys.readouterr().out == '{"metric": "stub", "n_gpus": 4}\n'   # rank 0's line, nothing else, on stdout
+    assert seen['cmd'][seen['cmd'].index('--nproc-per-node') + 1] == '4'
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_bench_gpus_n_end_to_end_with_a_stub_launcher(tmp_path):
+    """The whole door, in a real process: `python bench.py --gpus 2` with no WORLD_SIZE must reach torch.distributed.run
+    (here a stub `torch/distributed/run.py`-shaped module earlier on the path is not possible without shadowing torch, so the
+    child is the real launcher and the ranks fail where they should: at `bench.py needs an MI355X`, NOT at an assertion about
+    WORLD_SIZE) -- and the parent leaves with a non-zero code of the child's."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['MASTER_PORT'] = '29873'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--no-cpu-baseline', '--no-extras'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = r.stderr.decode()
+    assert r.returncode != 0
+    assert 'starting 2 ranks' in err
+    assert 'AssertionError' not in err
+    assert 'needs an MI355X' in err or 'HIP' in err or 'No HIP GPUs' in err or 'invalid device' in err, err[-2000:]
+    assert r.stdout.decode().strip() == ''                                # no JSON line from a failed run
+
+
 def _fake_node(tmp_path, gpu_numa=(0, 0, 0, 0, 1, 1, 1, 1), cpus_per_node=16):
     """A sysfs tree of a two-socket node: KFD nodes 0-1 are the CPUs, 2.. the GPUs (one PCI bus each)."""
     root = tmp_path / 'sysfs'
@@ -559,6 +619,21 @@ def test_numa_cpu_plan_on_a_two_socket_node(tmp_path):
     assert du.gpu_numa_nodes(root, env) == [1, 1]
     assert du.numa_cpu_plan(0, 2, sysfs=root, environ=env, current=set(range(32))) == set(range(16, 24))
     assert du.gpu_numa_nodes(root, {'HIP_VISIBLE_DEVICES': 'GPU-abcdef'}) == []
+    # HIP_ and CUDA_VISIBLE_DEVICES are two names of ONE filter on ROCm, not a composition: a launcher that sets both to the
+    # same list still means GPUs 4 and 5 (composing them raised IndexError or picked another GPU's node); HIP's wins
+    assert du.gpu_numa_nodes(root, {'HIP_VISIBLE_DEVICES': '4,5', 'CUDA_VISIBLE_DEVICES': '4,5'}) == [1, 1]
+    assert du.gpu_numa_nodes(root, {'HIP_VISIBLE_DEVICES': '1,0', 'CUDA_VISIBLE_DEVICES': '7,6'}) == [0, 0]
+    assert du.gpu_numa_nodes(root, {'ROCR_VISIBLE_DEVICES': '2,3,4,5', 'CUDA_VISIBLE_DEVICES': '2,3'}) == [1, 1]
+    # SMT: logical CPUs c and c + 8 of node 0 are the two threads of one core -- a rank gets WHOLE cores, never the sibling
+    # threads of another rank's cores
+    smt = _fake_node(tmp_path / 'smt')
+    for c in range(16):
+        d = os.path.join(smt, 'sys/devices/system/cpu/cpu%d/topology' % c)
+        os.makedirs(d)
+        with open(os.path.join(d, 'thread_siblings_list'), 'w') as f:
+            f.write('%d,%d\n' % (c % 8, c % 8 + 8))
+    sp = [du.numa_cpu_plan(r, 8, sysfs=smt, environ={}, current=set(range(32))) for r in range(4)]
+    assert sp == [{0, 8, 1, 9}, {2, 10, 3, 11}, {4, 12, 5, 13}, {6, 14, 7, 15}]
     # a container's mask that is already inside one node, an unknown NUMA node, no topology: hands off
     assert du.numa_cpu_plan(0, 8, sysfs=root, environ={}, current={0, 1, 2, 3}) is None
     assert du.numa_cpu_plan(0, 8, sysfs=_fake_node(tmp_path / 'b', gpu_numa=(-1,) * 8), environ={}, current=set(range(32))) is None
