@@ -118,8 +118,16 @@ __device__ __forceinline__ void leave_kernel(SyncWs* sync) {
     }
 }
 
+// The scalar offset is an OPAQUE zero (an s_mov the optimiser cannot see through).  Without it two hand-off loads of one
+// address are, to the compiler, the same value: the exchange ring is reached through a __restrict__ kernel argument, so not
+// even an asm "memory" barrier between them says that somebody else may have written it -- and the speculative protocol's
+// RE-load of a fragment that still held the canary was folded into the first load's result in one instantiation
+// (gru_bwd_persistent6_kernel<2, ..>, round 6: the retry loop spun on a stale register until the time-out; the instantiations
+// that shipped in rounds 2-5 happened to keep their re-loads -- their retry counters say so -- but nothing guaranteed it).
 __device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */);
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, zero, 16 /* sc1 */);
     return __builtin_bit_cast(f32x4, v);
 }
 // hand-off payload load (a timing experiment with plain, L2-allocating loads showed no difference; a run-time
@@ -249,6 +257,12 @@ __device__ __forceinline__ bool validate_fragments(f32x4 (&bf)[NCI][NGI], LoadFr
             break;
         }
     }
+    // Round 6: behind the re-load loop NOTHING is in flight.  The loop's exits are decided by scalar masks the compiler's
+    // wait-count pass cannot follow, so it merged "a re-issued load is this wave's YOUNGEST operation" into the join with the
+    // one-ballot fast path above and put a vmcnt(0) in front of the first MFMA of EVERY step -- the later fragments' staged
+    // consumption never happened on the fast path either (seen in the ISA of gru_fwd_persistent5_kernel: vmcnt(1), ballot,
+    // then vmcnt(0) before the first of the 64 MFMAs).  With this wait on the slow path only, the join needs none.
+    if constexpr (NCI * (G1 - G0) <= 2) wait_vmcnt0();
 validated:
     if (acc) {
         *acc |= retried;
@@ -2013,6 +2027,415 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent5_kernel(float* __
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// Backward recurrence, the d(h) HAND-OFF (round 6; B = 5 .. 12 at H = 32 RPW): the broadcast deal above with a third of the
+// bytes on the latency chain.
+//
+// Every backward kernel so far hands off d(gh) -- 3H values per batch row and step (K = 3H: gate g of unit j is k = g H + j).
+// But d(gh)_t[b, g, j] = dh_t[b, j] * c_g[t, b, j] with
+//     c_r = (1 - z)(1 - n^2) gh_n r (1 - r),   c_z = (h_prev - n) z (1 - z),   c_n = (1 - z)(1 - n^2) r
+// -- functions of the FORWARD pass's saved activations alone, known before the backward pass starts.  So the ring carries
+// dh_t (H values per row: the forward kernel's payload size), a consumer lane loads 4 consecutive units' dh once
+// (write-through stores, sc1 loads: the chain) and multiplies it by the three gates' coefficient fragments, which it
+// loaded ONE STEP AHEAD with plain cached loads from `coef` (T, B, 2, 3H) (written by the forward pass or by
+// gru_bwd_coef_kernel; off the chain, L2-served: every workgroup of a (direction, part) reads the same 9.6 KB per row).
+// The MFMAs, the partial-sum exchange through LDS, the four-lane gate role and the d(gi) / d(gh_n) outputs are the broadcast
+// deal's; only the k order changes: a wave owns RPW = H / 32 RUNS of 4 consecutive units (ring slot = [run][batch row][4]),
+// and an A register's 16 blocks are 16 (run, gate) ITEMS:
+//     registers 3 f + g, f < RPW / 16:   block b = (run 16 f + b, gate g)   -- one dh load feeds three registers
+//     the R = RPW % 16 last runs:        3 R items, gate-major, in ceil(3 R / 16) registers (one dh load each; the last
+//                                        register's items sit in its first ceil(L / 4) block COLUMNS, so that set A skips
+//                                        the instructions of the empty ones)
+// H = 800: 5 registers (3 + 2), 3 dh loads + 5 coefficient loads per lane and step, 19 + 10 + 5 instructions x 4.
+// ----------------------------------------------------------------------------------------------------------
+template <int RPW>
+struct DhDeal {
+    static constexpr int FT = RPW / 16, R = RPW % 16;
+    static constexpr int NREM = (3 * R + 15) / 16;
+    static constexpr int NREG = 3 * FT + NREM, NLOAD = FT + NREM;
+    static constexpr int L = 3 * R - 16 * (NREM - 1);           // items of the last register (R > 0)
+    static constexpr int NCOL = R > 0 ? (L + 3) / 4 : 4;        // block columns the last register uses
+    // set A / set B instruction (column a / pair member a) of register i: does any block it reads hold an item?
+    static constexpr bool col_used(int i, int a) { return (R == 0 || i < NREG - 1) ? true : a < NCOL; }
+    static constexpr int load_of(int i) { return i < 3 * FT ? i / 3 : FT + (i - 3 * FT); }
+};
+// item of (register i, block b): run inside the wave and gate, or false
+template <int RPW>
+__device__ __forceinline__ bool dh_item(int i, int b, int& run, int& gate) {
+    using D = DhDeal<RPW>;
+    if (i < 3 * D::FT) {
+        run = 16 * (i / 3) + b;
+        gate = i % 3;
+        return true;
+    }
+    const int m = i - 3 * D::FT;
+    int p;
+    if (m < D::NREM - 1) {
+        p = 16 * m + b;
+    } else {
+        const int a = b & 3, g = b >> 2;
+        if (a >= D::NCOL) return false;
+        const int pl = g * D::NCOL + a;
+        if (pl >= D::L) return false;
+        p = 16 * (D::NREM - 1) + pl;
+    }
+    gate = p / D::R;
+    run = 16 * D::FT + p % D::R;
+    return true;
+}
+
+// coef (T, B, 2, 3H) from the forward pass's saved tensors (G = (r, z, n), ghn = W_hn h, hout): an elementwise pass.  The
+// forward persistent kernels that take a `coef` pointer write the same values from their gate threads instead.
+__global__ __launch_bounds__(256) void gru_bwd_coef_kernel(const float* __restrict__ G, const float* __restrict__ ghn,
+                                                           const float* __restrict__ hout, float* __restrict__ coef,
+                                                           int T, int B, int H) {
+    const size_t n4 = (size_t)T * B * 2 * (H / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % (H / 4)) * 4;
+        const size_t row = i / (H / 4);                        // (t, b, dir)
+        const int dir = (int)(row & 1);
+        const size_t tb = row >> 1;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        const float* g = G + row * 3 * H + j;
+        const f32x4 r = *reinterpret_cast<const f32x4*>(g), z = *reinterpret_cast<const f32x4*>(g + H),
+                    n = *reinterpret_cast<const f32x4*>(g + 2 * H);
+        const f32x4 gn = *reinterpret_cast<const f32x4*>(ghn + row * H + j);
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+        if (tp >= 0 && tp < T) hp = *reinterpret_cast<const f32x4*>(hout + (((size_t)dir * T + tp) * B + b) * H + j);
+        f32x4 cr, cz, cn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float an = (1.f - z[e]) * (1.f - n[e] * n[e]);
+            cr[e] = an * gn[e] * r[e] * (1.f - r[e]);
+            cz[e] = (hp[e] - n[e]) * z[e] * (1.f - z[e]);
+            cn[e] = an * r[e];
+        }
+        float* c = coef + row * 3 * H + j;
+        *reinterpret_cast<f32x4*>(c) = cr;
+        *reinterpret_cast<f32x4*>(c + H) = cz;
+        *reinterpret_cast<f32x4*>(c + 2 * H) = cn;
+    }
+}
+
+#ifndef DS2_STAGE_GAP_BWD6
+#define DS2_STAGE_GAP_BWD6 4
+#endif
+template <int RPW, int NRG, int NPART = 3>
+__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __restrict__ G, float* __restrict__ ghn,
+                                                                       const float* __restrict__ hout,
+                                                                       const float* __restrict__ d_out,
+                                                                       const float* __restrict__ w_hh_t,
+                                                                       const float* __restrict__ coef,
+                                                                       SyncWs* __restrict__ sync, float* __restrict__ ring,
+                                                                       int T, int B, int H, int dbg, int spec) {
+    static_assert(NRG >= 4 && NRG <= 7 && NPART >= 2 && NPART <= 3, "broadcast deal: 16 .. 28 units per workgroup, 2 or 3 batch parts");
+    using D = DhDeal<RPW>;
+    constexpr int NREG = D::NREG, NLOAD = D::NLOAD;
+    constexpr int UNITS = 4 * NRG;
+    constexpr bool HASB = NRG >= 6, HASC = (NRG & 1) != 0;
+    constexpr int NSLOT = 4, CAHEAD = 2, SIGW = NWP - 1;
+    __shared__ __attribute__((aligned(16))) float red5[NRG * 16 * RED5_PITCH];
+    __shared__ int abort_flag;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
+    const int j0 = blockIdx.x * UNITS;
+    const int blk = lane >> 2, li = lane & 3, g = lane >> 4, q = (lane >> 2) & 3;
+    const int K = 3 * H;
+    const int bper = (B + NPART - 1) / NPART;
+    const int b0 = part * bper;
+    const int nb = min(bper, B - b0);                   // <= 4 (the launcher)
+    const int slot_floats = H * nb;                     // [run H / 4][batch row nb][4 units]
+    float* my_ring = ring + (size_t)(dir * NPART + part) * NSLOT * ((size_t)H * bper);
+    if (nb <= 0) {
+        if (tid == 0) leave_kernel(sync);
+        return;
+    }
+    if (tid == 0) abort_flag = 0;
+
+    // resident weights (B operands): component e of a register quad = unit 4 run + e of the item's gate
+    f32x4 wA[NREG][4], wB[HASB ? NREG : 1][2], wC[HASC ? NREG : 1];
+    {
+        auto wrow = [&](int rg) {
+            const int unit = j0 + 4 * rg + li;
+            return unit < H ? w_hh_t + ((size_t)dir * H + unit) * K : nullptr;
+        };
+        const float* rowA = wrow(q);
+        const float* rowB = wrow(4 + (q & 1));
+        const float* rowC = wrow(NRG - 1);
+        auto ld = [&](const float* row, int i, int b) {
+            int run, gate;
+            if (!row || !dh_item<RPW>(i, b, run, gate)) return f32x4{0.f, 0.f, 0.f, 0.f};
+            return *reinterpret_cast<const f32x4*>(row + gate * H + 4 * (RPW * wave + run));
+        };
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wA[i][a] = ld(rowA, i, 4 * g + a);
+            if constexpr (HASB) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wB[i][a] = ld(rowB, i, (blk & ~1) + a);
+            }
+            if constexpr (HASC) wC[i] = ld(rowC, i, blk);
+        }
+    }
+    // gate role: as gru_bwd_persistent5_kernel
+    const int u4 = tid & 3, gp = (tid >> 2) & 3, uq = (tid >> 4) % NRG, nn = (tid >> 4) / NRG;
+    const int gb = b0 + nn, gj = j0 + 4 * uq + u4;
+    const bool gate_ok = (nn < nb) && (gj < H);
+    float dhz = 0.f;
+    unsigned int* shards = &sync->arrive[dir][part][0][0];
+    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
+    // hand-off: the gp == 0 lane of a quad's first unit stores dh of the quad's four units -- ONE 16-byte payload per (run,
+    // batch row) and step (the d(gh) hand-off: three)
+    const bool storer = gate_ok && u4 == 0 && gp == 0;
+    const int ho = ((gj >> 2) * nb + (nn & 3)) * 4;                             // floats inside a slot
+    const u32x4 can4 = {CANARY_BITS, CANARY_BITS, CANARY_BITS, CANARY_BITS};
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, NSLOT * slot_floats * 4, 0x00020000);
+    if (storer) {                                       // slot 0 (and 1) may hold an earlier launch's payload
+#pragma unroll
+        for (int sl = 0; sl < CAHEAD; ++sl) store_sc1_b128(rs_w, (sl * slot_floats + ho) * 4, can4);
+    }
+    wait_vmcnt0();
+    __syncthreads();
+    if (tid == SIGW * 64) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == SIGW && !wait_arrivals(shards, 1, nslice, lane, &sync->error) && lane == 0) abort_flag = 1;
+    __syncthreads();
+    if (abort_flag) return;
+    int scur = 0, sprev = NSLOT - 1;
+    int spec_delay = spec & 0xFF, spec_clean = 0, nretry = 0;
+
+    // this lane's byte offsets: dh loads inside a ring slot, coefficient loads inside one time step's (B, 2, 3H) block
+    int loff[NLOAD], coff[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        int run, gate;
+        const bool ok = dh_item<RPW>(i, blk, run, gate) && li < nb;
+        const int rg = RPW * wave + run;                // run of the row: units 4 rg .. 4 rg + 3
+        // (a lane without an item, or past the batch, stages an element that exists: its dh fragment loads zeros and its weights
+        // are zeros, so what it multiplies them by only has to be finite)
+        coff[i] = ok ? ((((b0 + li) * 2 + dir) * 3 + gate) * H + 4 * rg) * 4 : ((b0 * 2 + dir) * 3 * H) * 4;
+        if (i % 3 == 0 || i >= 3 * D::FT) loff[D::load_of(i)] = ok ? ((rg * nb + li) * 4) * 4 : OOB_OFFSET;
+    }
+    auto red_at = [&](int rg, int unit, int part32) {
+        return red5 + ((rg * 4 + unit) * 4) * RED5_PITCH + ((part32 + 4 * ((unit >> 1) + 2 * rg)) & 31);
+    };
+    float* const redA = red_at(q, li, wave * 4 + g);
+    float* const redB = red_at(4 + (q & 1), li, wave * 4 + g);
+    float* const redC = red_at(NRG - 1, li, wave * 4 + g);
+    const float* const red_r = red5 + ((uq * 4 + u4) * 4 + nn) * RED5_PITCH + 8 * gp;
+
+    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
+    const long long tstep = dir == 0 ? -1 : 1;
+    const long long dG = tstep * B * 6 * H, dD = tstep * B * H, dN = tstep * B * 2 * H;
+    const int t_first = dir == 0 ? T - 1 : 0;
+    size_t of_g = (((size_t)t_first * B + gb) * 2 + dir) * 3 * H + gj;
+    size_t of_d = ((size_t)t_first * B + gb) * H + gj;
+    size_t of_n = (((size_t)t_first * B + gb) * 2 + dir) * H + gj;
+    size_t of_h = (((size_t)dir * T + t_first + tstep) * B + gb) * H + gj;
+    const int cstep_bytes = B * 6 * H * 4;             // one time step of coef
+    // Coefficient fragments: plain cached loads into registers at the TOP of the step that consumes them, in front of the
+    // first-attempt sleep and the dh loads.  An L2 / Infinity-Cache hit (0.1 - 0.25 us idle) returns under the sleep and the dh
+    // loads' own round trip; nothing is carried around the loop, the compiler counts the loads itself (they are older than the
+    // dh loads, so the vmcnt it emits for a dh fragment covers them).  Two other placements were built and measured first
+    // (profiles/r06_recurrence_experiments.md): a step ahead into loop-carried registers (the compiler copies the tuples at
+    // the loop's back edge behind a vmcnt(0): 3.0 us per step) and a step ahead by LDS-DMA (2.64 against the d(gh) form's 2.53:
+    // five DMA issues of ~100 cycles each and the read-back sit in the matrix phase).
+    auto load_coef1 = [&](__amdgpu_buffer_rsrc_t rs_c, int i) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, coff[i], 0, 0));
+    };
+    auto coef_rsrc = [&](int t) {                     // one time step of coef
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(coef) + (size_t)t * B * 6 * H, 0, cstep_bytes, 0x00020000);
+    };
+    auto early_loads = [&](int t, int next) {
+        dh = r = z = n = gn = hpv = 0.f;
+        if (gate_ok) {
+            const int tt = t + (next ? (int)tstep : 0);
+            const bool has_prev = dir == 0 ? (tt > 0) : (tt < T - 1);
+            const size_t g0 = of_g + (next ? dG : 0);
+            dh = d_out[of_d + (next ? dD : 0)];
+            r = G[g0];
+            z = G[g0 + H];
+            n = G[g0 + 2 * H];
+            gn = ghn[of_n + (next ? dN : 0)];
+            if (has_prev) hpv = hout[of_h + (next ? dD : 0)];
+        }
+    };
+    f32x4 cf[NREG];
+    {
+        const __amdgpu_buffer_rsrc_t rs_c0 = coef_rsrc(t_first);
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) cf[i] = load_coef1(rs_c0, i);
+        early_loads(t_first, 0);
+    }
+    int dead = 0;            // wave-uniform: a hand-off of this workgroup has timed out (the launch's results are void: finish quickly)
+    // one time step; FIRST: no matrix phase (nothing has been handed off yet).  Returns true when the launch was aborted.
+    auto step = [&](auto first_tag, const int s) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const int t = dir == 0 ? T - 1 - s : s;
+        DS2_WTICK(0);
+        DS2_WTICK(1);
+        if constexpr (!FIRST) {
+            // (ablation bits, fault-injection / timing builds only -- results WRONG: 2 = no hand-off loads and no MFMAs, 2048 = loads
+            // issued but not validated, 4096 = no MFMAs; the coefficient loads and multiplies stay in all of them)
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+                my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_c = coef_rsrc(t);       // this step's rows: they go with this step's dh
+            f32x4 bf[1][NLOAD];
+            auto load_frag = [&](int, int l) { bf[0][l] = LOAD_HANDOFF(rs_x, loff[l]); };
+            constexpr int SPLIT = D::FT > 0 && D::NREM > 0 ? D::FT : NLOAD;    // two stages: the full triples, then the last runs
+            if (!DS2_DBG(dbg, 2)) {
+                for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int l = 0; l < NLOAD; ++l) {
+                    if (DS2_STAGE_GAP_BWD6 > 0 && l == SPLIT && l > 0) __builtin_amdgcn_s_sleep(DS2_STAGE_GAP_BWD6);
+                    load_frag(0, l);
+                }
+            } else {
+#pragma unroll
+                for (int l = 0; l < NLOAD; ++l) bf[0][l] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_sched_barrier(0);             // every load out before the first MFMA
+            DS2_WTICK(2);
+            f32x4 accA[4], accB[2], accC;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) accA[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+            accB[0] = accB[1] = accC = f32x4{0.f, 0.f, 0.f, 0.f};
+            bool racc = false;
+            constexpr int NSTG = SPLIT < NLOAD ? 2 : 1;
+            static_for<0, NSTG>([&](auto st_tag) {
+                constexpr int st = decltype(st_tag)::value;
+                constexpr int L0 = st == 0 ? 0 : SPLIT, L1 = (NSTG == 1 || st == 1) ? NLOAD : SPLIT;
+                // (a stage's validation stays behind the previous stage's MFMAs: hoisted into them, its vmcnt wait stalls the
+                // wave in front of instructions whose operands have long arrived)
+                if constexpr (st > 0) __builtin_amdgcn_sched_barrier(0);
+                if (!dead && !DS2_DBG(dbg, 2048 | 2))
+                    validate_fragments<1, NLOAD, 0, L0, L1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag,
+                                                            nretry, &racc, st == NSTG - 1);
+                if (st == 0) DS2_WTICK(3);
+                static_for<0, NREG>([&](auto i_tag) {
+                    constexpr int i = decltype(i_tag)::value;
+                    if constexpr (D::load_of(i) >= L0 && D::load_of(i) < L1) {
+                        const f32x4 av = bf[0][D::load_of(i)] * cf[i];            // d(gh) of the lane's item: dh x coefficient
+                        // this register's coefficients for the NEXT matrix phase (they go with THIS step's dh), as soon as it
+                        // is free: the load runs under the MFMAs and the gate phase, a whole step ahead of its use
+                        cf[i] = load_coef1(rs_c, i);
+                        if (!DS2_DBG(dbg, 4096 | 2))
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            accA[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][0][e], accA[0], 2, 0, 0);
+                            if constexpr (D::col_used(i, 1)) accA[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][1][e], accA[1], 2, 1, 0);
+                            if constexpr (HASB) accB[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wB[i][0][e], accB[0], 1, 0, 0);
+                            if constexpr (D::col_used(i, 2)) accA[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][2][e], accA[2], 2, 2, 0);
+                            if constexpr (D::col_used(i, 3)) accA[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][3][e], accA[3], 2, 3, 0);
+                            if constexpr (HASB) accB[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wB[i][1][e], accB[1], 1, 1, 0);
+                            if constexpr (HASC) accC = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wC[i][e], accC, 0, 0, 0);
+                        }
+                    }
+                });
+            });
+            DS2_WTICK(4);
+            const f32x4 sa = (accA[0] + accA[1]) + (accA[2] + accA[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) redA[i * RED5_PITCH] = sa[i];
+            if constexpr (HASB) {
+                const f32x4 sb = accB[0] + accB[1];
+                float fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fb[i] = dpp_row_shr_add<8>(sb[i]);
+                if (q >= 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) redB[i * RED5_PITCH] = fb[i];
+                }
+            }
+            if constexpr (HASC) {
+                float fc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fc[i] = dpp_row_shr_add<8>(dpp_row_shr_add<4>(accC[i]));
+                if (q == 3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) redC[i * RED5_PITCH] = fc[i];
+                }
+            }
+        }
+        DS2_WTICK(5);
+        __syncthreads();
+        DS2_WTICK(6);
+        float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
+        {
+            float part = 0.f;
+            if constexpr (!FIRST) {
+                if (nn < 4) {                             // this gpart's 8 of the 32 partials
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(red_r), p1 = *reinterpret_cast<const f32x4*>(red_r + 4);
+                    const f32x4 ps = p0 + p1;
+                    part = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+                }
+                part = dpp_row_ror_add<4>(dpp_row_ror_add<8>(part));  // all four gparts: the same bits (see the broadcast deal)
+            }
+            if (gate_ok) {
+                dh += part + dhz;
+                const float dn_pre = dh * (1.f - z) * (1.f - n * n);
+                const float dz_pre = dh * (hpv - n) * z * (1.f - z);
+                const float dr_pre = dn_pre * gn * r * (1.f - r);
+                dhz = dh * z;
+                sv_r = dr_pre;
+                sv_z = dz_pre;
+                sv_n = dn_pre;
+                sv_g = dn_pre * r;
+            }
+        }
+        {
+            // dh of the quad's four units to its first lane: one 16-byte payload, one 16-byte canary
+            const float mine_v = not_canary(dh);
+            f32x4 v;
+            v[0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0x00, 0xF, 0xF, true));
+            v[1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0x55, 0xF, 0xF, true));
+            v[2] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0xAA, 0xF, 0xF, true));
+            v[3] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0xFF, 0xF, 0xF, true));
+            // The stores of the PREVIOUS step are complete before this step's payload goes out (see CANARY_BITS): a wave's
+            // vector-memory operations complete in issue order, this step's dh loads were issued behind those stores, and the
+            // matrix phase has consumed them -- no wait of its own.  Ablation builds that can skip the loads or their validation wait.
+            if (FIRST || DS2_DBG(dbg, 2 | 2048)) wait_vmcnt0();
+            DS2_WTICK(7);
+            if (storer) {
+                const bool lose = DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
+                if (!lose) store_sc1_b128(rs_w, (scur * slot_floats + ho) * 4, __builtin_bit_cast(u32x4, v));
+                store_sc1_b128(rs_w, (((scur + CAHEAD) & (NSLOT - 1)) * slot_floats + ho) * 4, can4);
+            }
+        }
+        const int aborted = abort_flag;                 // (issued here, consumed at the end of the step)
+        const size_t og = of_g, on = of_n;
+        // behind this step's payload: the next step's saved activations
+        if (s + 1 < T && !DS2_DBG(dbg, 8192)) early_loads(t, 1);
+        if (spec & (1 << 17)) wait_vmcnt0();            // self-timed: see spec_timing()
+        sprev = scur;
+        scur = (scur + 1) & (NSLOT - 1);
+        DS2_WTICK(8);
+        __syncthreads();
+        DS2_WTICK(9);
+        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: one plain store per lane, off the critical path
+            if (gp == 3) ghn[on] = sv_g;
+            else G[og + (size_t)gp * H] = gp == 0 ? sv_r : (gp == 1 ? sv_z : sv_n);
+        }
+        of_g += dG;
+        of_d += dD;
+        of_n += dN;
+        of_h += dD;
+        DS2_WTICK(10);
+        dead |= aborted;
+    };
+    // (no exit inside the loop: with one, the compiler routes it through the latch and copies every loop-carried register
+    // tuple there, behind a vmcnt(0).  A workgroup whose hand-off timed out stops validating and runs its remaining steps
+    // through -- its results are void anyway, the sticky error word is set -- instead of leaving)
+    step(std::true_type{}, 0);
+    for (int s = 1; s < T; ++s) step(std::false_type{}, s);
+    if (dead) return;
+    DS2_RETRY_FLUSH(nretry);
+    if (tid == SIGW * 64) leave_kernel(sync);
+}
+
+// ----------------------------------------------------------------------------------------------------------
 // Forward recurrence on v_mfma_f32_4x4x1_16b_f32 with A-operand broadcast (CBSZ / ABID; tools/mfma4x4_bcast_probe.hip:
 // blocks are grouped 2^CBSZ at a time and every block of a group takes its A rows from the group's block ABID).
 //
@@ -3052,6 +3475,21 @@ bool launch_bwd_persistent5(float* G, float* ghn, const float* hout, const float
     return false;
 }
 
+// the d(h) hand-off (gru_bwd_persistent6_kernel): H = 32 RPW, one batch quad per part, speculative hand-off
+template <int RPW, int NRG, int NPART = 3>
+bool launch_bwd_persistent6(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t, const float* coef,
+                            SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
+    dim3 grid(ds2_cdiv(H, 4 * NRG), 2, NPART), block(NWP * 64);
+    auto kern = &gru_bwd_persistent6_kernel<RPW, NRG, NPART>;
+    if (!grid_is_coresident(kern, grid, 0)) return false;
+    // (first-attempt delay and adaptation policy of THIS kernel: DS2_GRU_BWD6_SPEC = "delay,inc,log2clean" for A/B runs)
+    int d = 8, inc = 1, l2c = 5;
+    if (const char* e = getenv("DS2_GRU_BWD6_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
+    hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, coef, sync, ring, T, B, H, dbg,
+                       spec_timing(1, d, inc, l2c));
+    return true;
+}
+
 // Co-residency: every workgroup of a persistent launch spins on arrivals from all the others, so the whole grid must be
 // on the chip at once.  The budget is 15/16 of the CURRENT device's compute units (240 of an MI355X's 256: the rest
 // stays free for a concurrent RCCL kernel or the side stream), read once per device; a partitioned (CPX) or smaller
@@ -3341,6 +3779,64 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
     else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     if (!ok) {
         ds2_set_error("ds2_gru_bidir_bwd_persistent: the chosen kernel's grid is not co-resident on this device (B=%d H=%d)", B, H);
+        return DS2_ERR_UNSUPPORTED;
+    }
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}
+
+// ---- the d(h) hand-off backward recurrence (ABI revision 402) ---------------------------------------------------------------
+// Shapes it is built for: H = 800 (and H = 64, the test width), 5 <= B <= 12 -- the speculative one-quad-per-part forms.
+static bool dh_form_ok(int B, int H) {
+    return (H == 800 || H == 64) && B >= 5 && B <= 12 && persistent_ok(B, H);
+}
+extern "C" int ds2_gru_bwd_dh_supported(int B, int H) { return dh_form_ok(B, H) ? 1 : 0; }
+
+extern "C" int ds2_gru_bwd_coef(const float* G, const float* ghn, const float* hout, float* coef, int T, int B, int H,
+                                void* stream) {
+    DS2_CHECK_ARG(G && ghn && hout && coef);
+    DS2_CHECK_ARG(T > 0 && B > 0 && H > 0 && H % 4 == 0);
+    const size_t n4 = (size_t)T * B * 2 * (H / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gru_bwd_coef_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, ghn, hout, coef, T, B, H);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}
+
+extern "C" int ds2_gru_bidir_bwd_persistent_dh(float* G, float* ghn, const float* hout, const float* d_out,
+                                               const float* w_hh_t, const float* coef, void* sync_ws, int T, int B, int H,
+                                               int spare_cus, void* stream) {
+    DS2_CHECK_ARG(G && ghn && hout && d_out && w_hh_t && coef && sync_ws);
+    DS2_CHECK_ARG(T > 0 && B > 0 && H > 0);
+    if (!dh_form_ok(B, H)) {
+        ds2_set_error("ds2_gru_bidir_bwd_persistent_dh: unsupported shape B=%d H=%d", B, H);
+        return DS2_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    SyncWs* sync = (SyncWs*)sync_ws;
+    float* ring = (float*)((char*)sync_ws + header_bytes());
+    const int dbg = dbg_flags();
+    bool ok = false;
+#define DS2_BWD6_GO(RPW_, NRG_, NP_) launch_bwd_persistent6<RPW_, NRG_, NP_>(G, ghn, hout, d_out, w_hh_t, coef, sync, ring, T, B, H, dbg, st)
+    if (B >= 9) {                                       // three parts of one batch quad: units per workgroup by the CUs to leave free
+        const int cus = device_cus();
+        int want = spare_cus < 0 ? 52 : spare_cus;
+        const char* w = getenv("DS2_GRU_BWD_WIDE");
+        if (w && w[0] >= '0' && w[0] <= '2') want = w[0] == '0' ? 52 : (w[0] == '1' ? 82 : 0);
+        const int g20 = 6 * ds2_cdiv(H, 20), g24 = 6 * ds2_cdiv(H, 24), g28 = 6 * ds2_cdiv(H, 28);
+        if (H == 800) {
+            if (g20 <= max_persistent_wgs() && g20 > g24 && cus - g20 >= want) ok = DS2_BWD6_GO(25, 5, 3);
+            else if (cus - g24 >= want || g28 >= g24) ok = DS2_BWD6_GO(25, 6, 3);
+            else ok = DS2_BWD6_GO(25, 7, 3);
+        } else {
+            ok = want >= 80 ? DS2_BWD6_GO(2, 7, 3) : (want >= 40 ? DS2_BWD6_GO(2, 6, 3) : DS2_BWD6_GO(2, 5, 3));
+        }
+    } else {                                            // B = 5 .. 8: two parts, 16 units
+        ok = H == 800 ? DS2_BWD6_GO(25, 4, 2) : DS2_BWD6_GO(2, 4, 2);
+    }
+#undef DS2_BWD6_GO
+    if (!ok) {
+        ds2_set_error("ds2_gru_bidir_bwd_persistent_dh: the chosen kernel's grid is not co-resident on this device (B=%d H=%d)", B, H);
         return DS2_ERR_UNSUPPORTED;
     }
     DS2_CHECK_LAUNCH();

@@ -481,11 +481,24 @@ def gru_bidir_fwd(gates, w_hh, t, bsz, hid):
     return ghn, hout
 
 
-def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=-1):
+def gru_bwd_coef(gates, ghn, hout, t, bsz, hid):
+    """(T,B,2,3H) coefficient planes of the d(h) hand-off backward recurrence from the forward pass's saved tensors."""
+    coef = _empty((t, bsz, 2, 3 * hid), gates)
+    lib.call('ds2_gru_bwd_coef', gates, ghn, hout, coef, t, bsz, hid)
+    return coef
+
+
+def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=-1, coef=None):
     """``spare_cus``: compute units to leave free beside the launch for work queued on other streams (-1: the library's
     default; see ds2_gru_bidir_bwd_persistent_ex in include/ds2hip.h)."""
     if _use_persistent(gates.device, bsz, hid):
         try:
+            if coef is None and os.environ.get('DS2_GRU_BWD_DH', '0') == '1' and lib.query('ds2_gru_bwd_dh_supported', bsz, hid):
+                coef = gru_bwd_coef(gates, ghn, hout, t, bsz, hid)
+            if coef is not None:
+                lib.call('ds2_gru_bidir_bwd_persistent_dh', gates, ghn, hout, d_out, w_hh_t, coef,
+                         _gru_sync_ws(gates.device, bsz, hid), t, bsz, hid, int(spare_cus))
+                return
             lib.call('ds2_gru_bidir_bwd_persistent_ex', gates, ghn, hout, d_out, w_hh_t,
                      _gru_sync_ws(gates.device, bsz, hid), t, bsz, hid, int(spare_cus))
             return

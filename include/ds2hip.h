@@ -242,6 +242,20 @@ int ds2_gru_bidir_bwd_persistent(float* G, float* ghn, const float* hout, const 
  * Same results, same workspace; elsewhere the hint is ignored. */
 int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float* hout, const float* d_out,
                                     const float* w_hh_t, void* sync_ws, int T, int B, int H, int spare_cus, void* stream);
+/* The d(h) hand-off form of the backward recurrence (ABI revision 402; the reference: cuDNN's GRU backward under
+ * codes/model.py:51-52,62).  d(gh)_t[b, g, j] = dh_t[b, j] * c_g[t, b, j], where the three coefficient planes
+ *     c_r = (1 - z)(1 - n^2) gh_n r (1 - r),   c_z = (h_prev - n) z (1 - z),   c_n = (1 - z)(1 - n^2) r
+ * depend on the forward pass's saved activations only.  With `coef` (T, B, 2, 3H) = (c_r | c_z | c_n) per (t, b, direction)
+ * row given, the workgroups hand off dh_t (H values per batch row and step) instead of d(gh)_t (3H) and rebuild d(gh) at
+ * the consumer from coefficient fragments loaded a step ahead.  Same inputs / outputs / workspace / error contract as
+ * ds2_gru_bidir_bwd_persistent_ex; results equal up to fp32 rounding of the re-associated products.
+ *   ds2_gru_bwd_coef:          coef from G (= r, z, n), ghn, hout as ds2_gru_bidir_fwd* left them (an elementwise pass)
+ *   ds2_gru_bwd_dh_supported:  1 where the form is built (H = 800, 5 <= B <= 12; H = 64 for tests), else 0 -- the caller
+ *                              then uses ds2_gru_bidir_bwd_persistent_ex; the launch itself returns DS2_ERR_UNSUPPORTED */
+int ds2_gru_bwd_dh_supported(int B, int H);
+int ds2_gru_bwd_coef(const float* G, const float* ghn, const float* hout, float* coef, int T, int B, int H, void* stream);
+int ds2_gru_bidir_bwd_persistent_dh(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
+                                    const float* coef, void* sync_ws, int T, int B, int H, int spare_cus, void* stream);
 
 /* ------------------------------------------------------------------ output head helpers
  * softmax over the last dim of (rows, A) (eval branch, codes/model.py:204-205) and the argmax
