@@ -388,9 +388,11 @@ class DeepSpeech(nn.Module):
             w_hh = self._pair(r.weight_hh_l0, r.weight_hh_l0_reverse)               # (2*3H, H) view
             gates = ops.gemm(xin.view(rows, n_in), w_ih, trans_b=True)              # (T*B, 6H)
             self._tick('BatchNorm + input projection GEMM (forward)')
-            ghn, hout = ops.gru_bidir_fwd(gates, w_hh, t, bsz, hid)
+            # (a training pass also takes the backward recurrence's coefficient planes where its d(h)-hand-off form will run)
+            ghn, hout, coef = ops.gru_bidir_fwd(gates, w_hh, t, bsz, hid, want_coef=True) if need_grad else \
+                (ops.gru_bidir_fwd(gates, w_hh, t, bsz, hid) + (None,))
             self._tick('BiGRU recurrence forward')
-            rec.update(xin=xin, gates=gates, ghn=ghn, hout=hout)
+            rec.update(xin=xin, gates=gates, ghn=ghn, hout=hout, coef=coef)
             layers.append(rec)
             prev_h = hout
         head = self.fc[0].module
@@ -502,7 +504,7 @@ class DeepSpeech(nn.Module):
             # a grid that needs 240 of its 256 CUs resident at once: room for them there too)
             top_spare = 0 if grad_ready is None else top_layer_spare_cus()   # (a collective beside it: one CU per RCCL channel + 8)
             spare = (top_spare if li == nl - 1 else _BWD_SPARE_CUS) if side is not None else top_spare
-            ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid, spare_cus=spare)   # gates -> d(gi), ghn -> d(gh_n)
+            ops.gru_bidir_bwd(gates, ghn, hout, dy, w_hh_t, t, bsz, hid, spare_cus=spare, coef=rec.get('coef'))   # gates -> d(gi), ghn -> d(gh_n)
             self._tick('BiGRU recurrence backward (weight-gradient GEMMs beside it)')
             if pending is not None:
                 pending(gate)

@@ -2332,6 +2332,10 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __
                             if constexpr (HASB) accB[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wB[i][1][e], accB[1], 1, 1, 0);
                             if constexpr (HASC) accC = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wC[i][e], accC, 0, 0, 0);
                         }
+                        // (one coefficient load per register block, in this order: left alone the compiler issues all of a
+                        // stage's loads in one burst behind its MFMAs -- eight waves x 1 KB each at once back up the CU's one
+                        // texture-address path and the waves stall at issue: matrix phase 0.86 -> 1.15 us in the stamps)
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 });
             });
@@ -2958,6 +2962,7 @@ template <int KW, int UNITS, int P>
 __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        float* __restrict__ hout,
                                                                        const float* __restrict__ w_hh,
+                                                                       float* __restrict__ coef,
                                                                        SyncWs* __restrict__ sync, float* __restrict__ ring,
                                                                        int T, int B, int H, int dbg, int spec) {
     constexpr int ROWS = 3 * UNITS;                      // gate rows of the workgroup (<= 64)
@@ -3115,14 +3120,19 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
             gh_z = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_z));
             gh_n = dpp_quad_add<0x4E>(dpp_quad_add<0xB1>(gh_n));
         }
-        float h = 0.f, sv_a = 0.f;
+        float h = 0.f, sv_a = 0.f, sv_c = 0.f;
+        float c_r = 0.f, c_z = 0.f, c_n = 0.f, c_hp = 0.f;
         if (mine) {
             const float r = fast_sigmoid(gi_r + gh_r);
             const float z = fast_sigmoid(gi_z + gh_z);
             const float n = fast_tanh(gi_n + r * gh_n);
             h = (1.f - z) * n + z * hp;
-            hp = h;
             sv_a = gpart == 1 ? r : (gpart == 2 ? z : n);
+            c_r = r;
+            c_z = z;
+            c_n = n;
+            c_hp = hp;
+            hp = h;
         }
         {
             // the row's four units (lanes 0, 4, 8, 12 of the 16) to its first lane: one 16-byte payload, one 16-byte canary
@@ -3156,12 +3166,33 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
         // SLOWER without it, B = 10 / 12: 2.37 / 2.44 against 2.31-2.34 / 2.41: it keeps the eight waves' next hand-off loads together)
         __syncthreads();
         DS2_WTICK(9);
-        if (mine) {   // saved activations: read by later launches only, off the critical path
-            if (gpart == 0) {
-                hout[oo] = h;
-                ghn[on] = gh_n;
-            } else {
-                G[og + (size_t)(gpart - 1) * H] = sv_a;
+        {
+            // Saved activations: read by later launches only, off the critical path.  Round 6: four consecutive units of one
+            // plane and batch row = 16 contiguous bytes, gathered with DPP to the row's first unit's lane (as the payload is)
+            // and stored as ONE dwordx4 -- gpart 0: hout (and gh_n), gparts 1 .. 3: the r / z / n planes (and the three
+            // coefficient planes): two store instructions of a quarter of the lanes per wave and step, where dword stores
+            // were four of three quarters of them (with the coefficient planes; they cost 2.12 -> 2.21 us per step that way).
+            // The backward recurrence's coefficient planes (gru_bwd_persistent6_kernel; the expressions of gru_bwd_coef_kernel), behind
+            // the end-of-step barrier with the saved-activation stores.  Their dozen instructions and one store are work in
+            // front of the NEXT step's first-attempt sleep, which only has to shrink by as much -- but that sleep adapts by one
+            // s_sleep per 2^k clean steps: with the launch's usual start (8 sleeps, k = 6) the planes cost 0.10 us per step
+            // whichever half of them (the arithmetic, the store) was compiled in; started at 3 sleeps they cost 0.01
+            // (launch_fwd_persistent5).
+            if (coef) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (mine) {
+                    const float an = (1.f - c_z) * (1.f - c_n * c_n);
+                    sv_c = gpart == 1 ? an * gh_n * c_r * (1.f - c_r) : (gpart == 2 ? (c_hp - c_n) * c_z * (1.f - c_z) : an * c_r);
+                }
+            }
+            const float x1 = gpart == 0 ? h : sv_a, x2 = gpart == 0 ? gh_n : sv_c;
+            const f32x4 v1 = {x1, dpp_row_shl<4>(x1), dpp_row_shl<8>(x1), dpp_row_shl<12>(x1)};
+            const f32x4 v2 = {x2, dpp_row_shl<4>(x2), dpp_row_shl<8>(x2), dpp_row_shl<12>(x2)};
+            if (mine && (tid & 12) == 0) {                // the first of the row's four units (all four exist: H % 4 == 0)
+                float* const p1 = gpart == 0 ? hout + oo : G + og + (size_t)(gpart - 1) * H;
+                *reinterpret_cast<f32x4*>(p1) = v1;
+                if (gpart == 0) *reinterpret_cast<f32x4*>(ghn + on) = v2;
+                else if (coef) *reinterpret_cast<f32x4*>(coef + og + (size_t)(gpart - 1) * H) = v2;
             }
         }
         DS2_WTICK(10);
@@ -3404,16 +3435,21 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
 
 // the row deal (gru_fwd_persistent5_kernel): three batch parts of one quad each, 20 units per workgroup, H = 8 KW
 template <int KW, int P = 3>
-bool launch_fwd_persistent5(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
-                            int H, int dbg, hipStream_t st) {
+bool launch_fwd_persistent5(float* G, float* ghn, float* hout, const float* w_hh, float* coef, SyncWs* sync, float* ring, int T,
+                            int B, int H, int dbg, hipStream_t st) {
     constexpr int UNITS = 20;
     dim3 grid(ds2_cdiv(H, UNITS), 2, P), block(NWP * 64);
     auto kern = &gru_fwd_persistent5_kernel<KW, UNITS, P>;
     if (!grid_is_coresident(kern, grid, 0)) return false;
     // (first-attempt delay and adaptation policy of THIS kernel: DS2_GRU_FWD5_SPEC = "delay,inc,log2clean" for A/B runs)
+    // With the coefficient planes as an output (a training pass whose backward recurrence hands off dh) a step has more work
+    // behind its payload store and wants a shorter sleep from the start -- measured at B = 10 / 9, us per forward step with the
+    // planes, (8, 1, 6) -> (3, 1, 5): 2.27 / 2.16 -> 2.16 / 2.08 (without the planes: 2.15 at B = 10 either way); B = 12 (three full
+    // quads) is the exception: 2.32 -> 2.48
     int d = 8, inc = 1, l2c = 6;
+    if (coef && B <= 11) d = 3, l2c = 5;
     if (const char* e = getenv("DS2_GRU_FWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
-    hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, spec_timing(0, d, inc, l2c));
+    hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, w_hh, coef, sync, ring, T, B, H, dbg, spec_timing(0, d, inc, l2c));
     return true;
 }
 
@@ -3594,8 +3630,20 @@ extern "C" size_t ds2_gru_sync_error_offset(void) { return offsetof(SyncWs, erro
 
 extern "C" int ds2_gru_persistent_supported(int B, int H) { return persistent_ok(B, H) ? 1 : 0; }
 
+extern "C" int ds2_gru_bwd_coef(const float* G, const float* ghn, const float* hout, float* coef, int T, int B, int H,
+                                void* stream);
+extern "C" int ds2_gru_bidir_fwd_persistent_ex(float* G, float* ghn, float* hout, const float* w_hh, float* coef,
+                                               void* sync_ws, int T, int B, int H, void* stream);
 extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh, void* sync_ws,
                                             int T, int B, int H, void* stream) {
+    return ds2_gru_bidir_fwd_persistent_ex(G, ghn, hout, w_hh, nullptr, sync_ws, T, B, H, stream);
+}
+
+// coef != NULL: (T, B, 2, 3H), filled with the d(h)-hand-off backward recurrence's coefficient planes (see
+// gru_bwd_persistent6_kernel) -- by the forward kernel's own gate threads where the form that runs has that output (the row
+// deal: B = 9 .. 12 at H = 800), by an elementwise pass behind it on the same stream otherwise.
+extern "C" int ds2_gru_bidir_fwd_persistent_ex(float* G, float* ghn, float* hout, const float* w_hh, float* coef,
+                                               void* sync_ws, int T, int B, int H, void* stream) {
     DS2_CHECK_ARG(G && ghn && hout && w_hh && sync_ws);
     DS2_CHECK_ARG(T > 0 && B > 0 && H > 0);
     if (!persistent_ok(B, H)) {
@@ -3642,7 +3690,10 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
             // the row deal where it is built (H = 800: 100 columns per wave); DS2_GRU_FWD_ROWS = 0: the k-balanced deal (A/B timing)
             const char* rows = getenv("DS2_GRU_FWD_ROWS");
             if (H == 800 && bper <= 4 && !(rows && rows[0] == '0'))
-                ok = launch_fwd_persistent5<100>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+            {
+                ok = launch_fwd_persistent5<100>(G, ghn, hout, w_hh, coef, sync, ring, T, B, H, dbg, st);
+                if (ok) coef = nullptr;                   // written by the kernel itself
+            }
             else
                 ok = launch_fwd_persistent4<3, 1, 2, 5>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
         }
@@ -3669,6 +3720,7 @@ extern "C" int ds2_gru_bidir_fwd_persistent(float* G, float* ghn, float* hout, c
         return DS2_ERR_UNSUPPORTED;
     }
     DS2_CHECK_LAUNCH();
+    if (coef) return ds2_gru_bwd_coef(G, ghn, hout, coef, T, B, H, stream);
     return DS2_OK;
 }
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     'ds2_gru_bidir_bwd_persistent': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ds2_gru_bidir_bwd_persistent_ex': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'ds2_gru_bwd_dh_supported': (_I, [_I, _I]),
+    'ds2_gru_bidir_fwd_persistent_ex': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ds2_gru_bwd_coef': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'ds2_gru_bidir_bwd_persistent_dh': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'ds2_softmax_rows': (_I, [_P, _I, _I, _P, _P]),

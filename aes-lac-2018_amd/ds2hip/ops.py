@@ -464,21 +464,37 @@ def check_async_errors():
             raise_async_error()
 
 
-def gru_bidir_fwd(gates, w_hh, t, bsz, hid):
-    """gates (T,B,2,3H) holds gi on entry, (r,z,n) on exit.  Returns (ghn (T,B,2,H), hout (2,T,B,H))."""
+def gru_bwd_dh_wanted(dev, bsz, hid):
+    """Will ``gru_bidir_bwd`` run the d(h)-hand-off backward recurrence for this shape (so that the training forward pass
+    should ask for the coefficient planes)?  Default: where the library has the form AND the forward kernel writes the planes
+    itself (B = 9 .. 12 at H = 800: measured stand-alone at B = 10, us per step, d(gh) -> d(h) hand-off: 2.55 -> 2.36 on 240
+    workgroups, 2.81 -> 2.67 on 174); for B = 5 .. 8 the planes would cost an extra elementwise pass that eats the
+    0.03 us per step the form gains there.  ``DS2_GRU_BWD_DH`` = 0 / 1 forces it off / on wherever the form exists."""
+    if not _use_persistent(dev, bsz, hid) or not lib.query('ds2_gru_bwd_dh_supported', bsz, hid):
+        return False
+    e = os.environ.get('DS2_GRU_BWD_DH')
+    if e in ('0', '1'):
+        return e == '1'
+    return bsz >= 9
+
+
+def gru_bidir_fwd(gates, w_hh, t, bsz, hid, want_coef=False):
+    """gates (T,B,2,3H) holds gi on entry, (r,z,n) on exit.  Returns (ghn (T,B,2,H), hout (2,T,B,H)), and with ``want_coef``
+    also the (T,B,2,3H) coefficient planes of the d(h)-hand-off backward recurrence (None where that form will not run)."""
     ghn = _empty((t, bsz, 2, hid), gates)
     hout = _empty((2, t, bsz, hid), gates)
+    coef = _empty((t, bsz, 2, 3 * hid), gates) if want_coef and gru_bwd_dh_wanted(gates.device, bsz, hid) else None
     if _use_persistent(gates.device, bsz, hid):
         try:
-            lib.call('ds2_gru_bidir_fwd_persistent', gates, ghn, hout, w_hh, _gru_sync_ws(gates.device, bsz, hid), t,
+            lib.call('ds2_gru_bidir_fwd_persistent_ex', gates, ghn, hout, w_hh, coef, _gru_sync_ws(gates.device, bsz, hid), t,
                      bsz, hid)
-            return ghn, hout
+            return (ghn, hout, coef) if want_coef else (ghn, hout)
         except lib.Ds2Error as e:               # nothing was launched: the chosen kernel's grid is not co-resident here
             if e.code != lib.ERR_UNSUPPORTED or GRU_MODE == 'persistent':
                 raise
             _disable_persistent(gates.device, str(e))
     lib.call('ds2_gru_bidir_fwd', gates, ghn, hout, w_hh, t, bsz, hid)
-    return ghn, hout
+    return (ghn, hout, None) if want_coef else (ghn, hout)     # (the launch-per-step backward kernels take no coefficients)
 
 
 def gru_bwd_coef(gates, ghn, hout, t, bsz, hid):
@@ -490,11 +506,10 @@ def gru_bwd_coef(gates, ghn, hout, t, bsz, hid):
 
 def gru_bidir_bwd(gates, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=-1, coef=None):
     """``spare_cus``: compute units to leave free beside the launch for work queued on other streams (-1: the library's
-    default; see ds2_gru_bidir_bwd_persistent_ex in include/ds2hip.h)."""
+    default; see ds2_gru_bidir_bwd_persistent_ex in include/ds2hip.h).  ``coef``: the forward pass's coefficient planes
+    (``gru_bidir_fwd(.., want_coef=True)``) -> the d(h)-hand-off form; None -> the d(gh)-hand-off form."""
     if _use_persistent(gates.device, bsz, hid):
         try:
-            if coef is None and os.environ.get('DS2_GRU_BWD_DH', '0') == '1' and lib.query('ds2_gru_bwd_dh_supported', bsz, hid):
-                coef = gru_bwd_coef(gates, ghn, hout, t, bsz, hid)
             if coef is not None:
                 lib.call('ds2_gru_bidir_bwd_persistent_dh', gates, ghn, hout, d_out, w_hh_t, coef,
                          _gru_sync_ws(gates.device, bsz, hid), t, bsz, hid, int(spare_cus))

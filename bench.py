@@ -277,9 +277,9 @@ def gru_pass_roofline(model, bsz, t):
         torch.cuda.synchronize()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
-        ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
+        ghn, hout, coef = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid, want_coef=True)       # as a training pass launches them
         e[1].record()
-        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=0 if rep % 2 == 0 else _BWD_SPARE_CUS)
+        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=0 if rep % 2 == 0 else _BWD_SPARE_CUS, coef=coef)
         e[2].record()
         torch.cuda.synchronize()
         ops.check_async_errors()

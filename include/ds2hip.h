@@ -253,6 +253,11 @@ int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float* hout, con
  *   ds2_gru_bwd_dh_supported:  1 where the form is built (H = 800, 5 <= B <= 12; H = 64 for tests), else 0 -- the caller
  *                              then uses ds2_gru_bidir_bwd_persistent_ex; the launch itself returns DS2_ERR_UNSUPPORTED */
 int ds2_gru_bwd_dh_supported(int B, int H);
+/* ds2_gru_bidir_fwd_persistent with the coefficient planes as a fourth output: coef (T, B, 2, 3H) or NULL.  Where the forward
+ * form that runs can (B = 9 .. 12 at H = 800) its own gate threads write them; otherwise ds2_gru_bwd_coef runs behind the
+ * launch on the same stream.  A training forward pass that will call ds2_gru_bidir_bwd_persistent_dh asks for them here. */
+int ds2_gru_bidir_fwd_persistent_ex(float* G, float* ghn, float* hout, const float* w_hh, float* coef, void* sync_ws, int T,
+                                    int B, int H, void* stream);
 int ds2_gru_bwd_coef(const float* G, const float* ghn, const float* hout, float* coef, int T, int B, int H, void* stream);
 int ds2_gru_bidir_bwd_persistent_dh(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                                     const float* coef, void* sync_ws, int T, int B, int H, int spare_cus, void* stream);

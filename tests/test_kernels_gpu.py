@@ -589,6 +589,71 @@ def test_gru_backward_forms_by_spare_cus_match_step_kernels(ops, monkeypatch, bs
     _long_sequence_case(ops, monkeypatch, bsz, 6, spare_cus=(0, 82, 52))
 
 
+def _dh_case(ops, monkeypatch, t, bsz, hid, spare_cus, reps=2, own_coef=True):
+    """The d(h)-hand-off backward recurrence (ds2_gru_bidir_bwd_persistent_dh) against the launch-per-step kernels AND against
+    the d(gh)-hand-off form on the same forward pass."""
+    torch.manual_seed(3 * t + bsz)
+    k = 1.0 / hid ** 0.5
+    w_hh = ((torch.rand(2, 3 * hid, hid) * 2 - 1) * k).to(DEV)
+    w_hh_t = torch.stack([ops.transpose2d(w_hh[0], 3 * hid, hid), ops.transpose2d(w_hh[1], 3 * hid, hid)], 0)
+    gi = torch.randn(t, bsz, 2, 3 * hid).to(DEV)
+    d_out = (0.1 * torch.randn(t, bsz, hid)).to(DEV)
+    monkeypatch.setattr(ops, 'GRU_MODE', 'step')
+    g = gi.clone()
+    ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
+    ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
+    torch.cuda.synchronize()
+    ref = (g, ghn)
+    monkeypatch.setattr(ops, 'GRU_MODE', 'persistent')
+    monkeypatch.setenv('DS2_GRU_BWD_DH', '1')
+    assert ops.gru_bwd_dh_wanted(gi.device, bsz, hid)
+    for rep in range(reps):
+        for spare in spare_cus:
+            g = gi.clone()
+            ghn, hout, coef = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid, want_coef=True)
+            assert coef is not None
+            # the planes the forward launch produced (its own gate threads at B = 9 .. 12, H = 800; the elementwise pass
+            # elsewhere) against the elementwise pass run here on the same saved tensors
+            again = ops.gru_bwd_coef(g, ghn, hout, t, bsz, hid)
+            scale = max(float(again.abs().max()), 1.0)
+            assert float((coef - again).abs().max()) <= 2e-6 * scale
+            ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=spare, coef=coef if own_coef else again)
+            torch.cuda.synchronize()
+            ops.check_async_errors()
+            for a, b in zip((g, ghn), ref):
+                scale = max(float(b.abs().max()), 1.0)
+                assert float((a - b).abs().max()) <= 2e-4 * scale
+    assert not ops._persistent_off
+
+
+@pytest.mark.parametrize('bsz', [5, 8, 9, 10, 12])
+def test_gru_backward_dh_handoff_matches_step_kernels_long_sequence(ops, monkeypatch, bsz):
+    """T = 746 at the real width: every form of the d(h)-hand-off kernel (two parts of 16 units for B = 5 .. 8; three parts of
+    20 / 24 / 28 units for B = 9 .. 12, chosen by spare_cus), twice each, interleaved on ONE exchange workspace with the forward
+    launches.  A stale dh fragment or a coefficient fragment of the wrong step is an O(1) difference."""
+    _dh_case(ops, monkeypatch, 746, bsz, 800, (0, 82, 52) if bsz >= 9 else (-1,))
+
+
+@pytest.mark.parametrize('t,bsz', [(1, 10), (2, 9), (7, 12), (9, 5), (33, 8)])
+def test_gru_backward_dh_handoff_short_sequences_and_narrow_width(ops, monkeypatch, t, bsz):
+    """T = 1 (the peeled first step only), T = 2, odd lengths; H = 64 (2 runs per wave: one partly filled register)."""
+    _dh_case(ops, monkeypatch, t, bsz, 64, (0, 82) if bsz >= 9 else (-1,), reps=1)
+    _dh_case(ops, monkeypatch, t, bsz, 800, (82,) if bsz >= 9 else (-1,), reps=1, own_coef=False)
+
+
+def test_gru_backward_dh_handoff_is_the_default_where_the_forward_kernel_writes_the_planes(ops, monkeypatch):
+    monkeypatch.delenv('DS2_GRU_BWD_DH', raising=False)
+    monkeypatch.setattr(ops, 'GRU_MODE', 'persistent')
+    dev = torch.device(DEV)
+    assert ops.gru_bwd_dh_wanted(dev, 10, 800) and ops.gru_bwd_dh_wanted(dev, 9, 800) and ops.gru_bwd_dh_wanted(dev, 12, 800)
+    assert not ops.gru_bwd_dh_wanted(dev, 8, 800) and not ops.gru_bwd_dh_wanted(dev, 13, 800) and not ops.gru_bwd_dh_wanted(dev, 10, 256)
+    monkeypatch.setenv('DS2_GRU_BWD_DH', '0')
+    assert not ops.gru_bwd_dh_wanted(dev, 10, 800)
+    monkeypatch.setattr(ops, 'GRU_MODE', 'step')
+    monkeypatch.delenv('DS2_GRU_BWD_DH', raising=False)
+    assert not ops.gru_bwd_dh_wanted(dev, 10, 800)
+
+
 @pytest.mark.parametrize('bsz,fwd_bf16,bwd_bf16', [(17, '0', '0'), (32, '0', '0'), (64, '0', '0'), (17, '1', '1'), (32, '1', '1'),
                                                    (64, '1', '1')])
 def test_gru_two_part_forms_f32_and_split_operand_families(ops, monkeypatch, bsz, fwd_bf16, bwd_bf16):

@@ -26,8 +26,10 @@ for bsz in [int(a) for a in sys.argv[1:]] or [10]:
             times = []
             for rep in range(1 if form == 'step' else 5):
                 g = gi.clone()
-                ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid)
-                coef = ops.gru_bwd_coef(g, ghn, hout, t, bsz, hid) if form == 'dh' else None
+                os.environ['DS2_GRU_BWD_DH'] = '1' if form == 'dh' else '0'
+                ghn, hout, coef = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid, want_coef=True)
+                if form == 'dh' and os.environ.get('COEF_PASS') == '1':       # the elementwise pass instead of the forward kernel's own
+                    coef = ops.gru_bwd_coef(g, ghn, hout, t, bsz, hid)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

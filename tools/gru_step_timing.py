@@ -16,8 +16,8 @@ res = {'fwd': [], 'bwd': []}
 for _ in range(6):
     g = gates.clone(); torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    e[0].record(); ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid); e[1].record()
-    ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=spare); e[2].record(); torch.cuda.synchronize()
+    e[0].record(); ghn, hout, coef = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid, want_coef=True); e[1].record()
+    ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=spare, coef=coef); e[2].record(); torch.cuda.synchronize()
     res['fwd'].append(e[0].elapsed_time(e[1])*1e3/t); res['bwd'].append(e[1].elapsed_time(e[2])*1e3/t)
 print('T=%d ' % t, end='')
 print('DBG=%s B=%d spare_cus=%d  fwd %.2f us/step  bwd %.2f us/step' % (os.environ.get('DS2_GRU_DBG','0'), bsz, spare, np.median(res['fwd']), np.median(res['bwd'])))

@@ -28,9 +28,9 @@ for it in range(4):
         rr(ctypes.addressof(nretry), 1)            # reset: count the last pass only
     g = gates.clone(); torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    e[0].record(); ghn, hout = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid); e[1].record()
+    e[0].record(); ghn, hout, coef = ops.gru_bidir_fwd(g, w_hh, t, bsz, hid, want_coef=True); e[1].record()
     if which == 'bwd':
-        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid)
+        ops.gru_bidir_bwd(g, ghn, hout, d_out, w_hh_t, t, bsz, hid, spare_cus=int(os.environ.get("SPARE_CUS", "-1")), coef=coef)
     e[2].record(); torch.cuda.synchronize()
     times.append(e[0].elapsed_time(e[1]) * 1e3 / t if which == 'fwd' else e[1].elapsed_time(e[2]) * 1e3 / t)
 us_step = float(np.median(times))
