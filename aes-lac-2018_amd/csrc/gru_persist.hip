@@ -2120,7 +2120,12 @@ __global__ __launch_bounds__(256) void gru_bwd_coef_kernel(const float* __restri
 #ifndef DS2_STAGE_GAP_BWD6
 #define DS2_STAGE_GAP_BWD6 4
 #endif
-template <int RPW, int NRG, int NPART = 3>
+// ABL: ablation bits (results WRONG) as a COMPILE-TIME parameter, instantiated only in the fault-injection / timing builds and
+// chosen by the launcher from DS2_GRU_DBG there -- 2: no hand-off loads and no MFMAs (the skeleton: the coefficient loads and
+// multiplies stay), 2048: loads issued but not validated, 4096: no MFMAs, 8192: no prefetch of the next step's saved
+// activations.  (As run-time branches they cost the UNABLATED launch of those builds 0.9 us per step: a branch around the dh
+// loads makes the fragments two-path values, a branch per MFMA block splits the stream.)
+template <int RPW, int NRG, int NPART = 3, int ABL = 0>
 __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __restrict__ G, float* __restrict__ ghn,
                                                                        const float* __restrict__ hout,
                                                                        const float* __restrict__ d_out,
@@ -2134,6 +2139,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __
     constexpr int UNITS = 4 * NRG;
     constexpr bool HASB = NRG >= 6, HASC = (NRG & 1) != 0;
     constexpr int NSLOT = 4, CAHEAD = 2, SIGW = NWP - 1;
+    constexpr bool NOLOAD = (ABL & 2) != 0, NOVAL = (ABL & (2048 | 2)) != 0, NOMFMA = (ABL & (4096 | 2)) != 0, NOPF = (ABL & 8192) != 0;
     __shared__ __attribute__((aligned(16))) float red5[NRG * 16 * RED5_PITCH];
     __shared__ int abort_flag;
 
@@ -2277,15 +2283,13 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __
         DS2_WTICK(0);
         DS2_WTICK(1);
         if constexpr (!FIRST) {
-            // (ablation bits, fault-injection / timing builds only -- results WRONG: 2 = no hand-off loads and no MFMAs, 2048 = loads
-            // issued but not validated, 4096 = no MFMAs; the coefficient loads and multiplies stay in all of them)
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
                 my_ring + (size_t)sprev * slot_floats, 0, slot_floats * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_c = coef_rsrc(t);       // this step's rows: they go with this step's dh
             f32x4 bf[1][NLOAD];
             auto load_frag = [&](int, int l) { bf[0][l] = LOAD_HANDOFF(rs_x, loff[l]); };
             constexpr int SPLIT = D::FT > 0 && D::NREM > 0 ? D::FT : NLOAD;    // two stages: the full triples, then the last runs
-            if (!DS2_DBG(dbg, 2)) {
+            if constexpr (!NOLOAD) {
                 for (int i = 0; i < spec_delay; ++i) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int l = 0; l < NLOAD; ++l) {
@@ -2310,34 +2314,44 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __
                 // (a stage's validation stays behind the previous stage's MFMAs: hoisted into them, its vmcnt wait stalls the
                 // wave in front of instructions whose operands have long arrived)
                 if constexpr (st > 0) __builtin_amdgcn_sched_barrier(0);
-                if (!dead && !DS2_DBG(dbg, 2048 | 2))
-                    validate_fragments<1, NLOAD, 0, L0, L1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag,
+                if constexpr (!NOVAL)
+                    if (!dead)
+                        validate_fragments<1, NLOAD, 0, L0, L1>(bf, load_frag, true, spec, spec_delay, spec_clean, sync, abort_flag,
                                                             nretry, &racc, st == NSTG - 1);
                 if (st == 0) DS2_WTICK(3);
-                static_for<0, NREG>([&](auto i_tag) {
-                    constexpr int i = decltype(i_tag)::value;
-                    if constexpr (D::load_of(i) >= L0 && D::load_of(i) < L1) {
-                        const f32x4 av = bf[0][D::load_of(i)] * cf[i];            // d(gh) of the lane's item: dh x coefficient
-                        // this register's coefficients for the NEXT matrix phase (they go with THIS step's dh), as soon as it
-                        // is free: the load runs under the MFMAs and the gate phase, a whole step ahead of its use
-                        cf[i] = load_coef1(rs_c, i);
-                        if (!DS2_DBG(dbg, 4096 | 2))
+                auto reg_blocks = [&](auto mfma_tag) {
+                    constexpr bool MFMA = decltype(mfma_tag)::value;
+                    static_for<0, NREG>([&](auto i_tag) {
+                        constexpr int i = decltype(i_tag)::value;
+                        if constexpr (D::load_of(i) >= L0 && D::load_of(i) < L1) {
+                            const f32x4 av = bf[0][D::load_of(i)] * cf[i];        // d(gh) of the lane's item: dh x coefficient
+                            // this register's coefficients for the NEXT matrix phase (they go with THIS step's dh), as soon as
+                            // it is free: the load runs under the MFMAs and the gate phase, a whole step ahead of its use
+                            // (the ablations without MFMAs keep step 0's coefficients: with nothing to run under, these loads'
+                            // latency would be what the shortened step measures)
+                            if constexpr (MFMA) cf[i] = load_coef1(rs_c, i);
+                            if constexpr (MFMA) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            accA[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][0][e], accA[0], 2, 0, 0);
-                            if constexpr (D::col_used(i, 1)) accA[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][1][e], accA[1], 2, 1, 0);
-                            if constexpr (HASB) accB[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wB[i][0][e], accB[0], 1, 0, 0);
-                            if constexpr (D::col_used(i, 2)) accA[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][2][e], accA[2], 2, 2, 0);
-                            if constexpr (D::col_used(i, 3)) accA[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][3][e], accA[3], 2, 3, 0);
-                            if constexpr (HASB) accB[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wB[i][1][e], accB[1], 1, 1, 0);
-                            if constexpr (HASC) accC = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wC[i][e], accC, 0, 0, 0);
+                                for (int e = 0; e < 4; ++e) {
+                                    accA[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][0][e], accA[0], 2, 0, 0);
+                                    if constexpr (D::col_used(i, 1)) accA[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][1][e], accA[1], 2, 1, 0);
+                                    if constexpr (HASB) accB[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wB[i][0][e], accB[0], 1, 0, 0);
+                                    if constexpr (D::col_used(i, 2)) accA[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][2][e], accA[2], 2, 2, 0);
+                                    if constexpr (D::col_used(i, 3)) accA[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wA[i][3][e], accA[3], 2, 3, 0);
+                                    if constexpr (HASB) accB[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wB[i][1][e], accB[1], 1, 1, 0);
+                                    if constexpr (HASC) accC = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], wC[i][e], accC, 0, 0, 0);
+                                }
+                            } else {
+                                accC[0] += av[0] + av[1] + av[2] + av[3];         // (keeps the products alive)
+                            }
+                            // (one coefficient load per register block, in this order: left alone the compiler issues all of a
+                            // stage's loads in one burst behind its MFMAs -- eight waves x 1 KB each at once back up the CU's one
+                            // texture-address path and the waves stall at issue: matrix phase 0.86 -> 1.15 us in the stamps)
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        // (one coefficient load per register block, in this order: left alone the compiler issues all of a
-                        // stage's loads in one burst behind its MFMAs -- eight waves x 1 KB each at once back up the CU's one
-                        // texture-address path and the waves stall at issue: matrix phase 0.86 -> 1.15 us in the stamps)
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                });
+                    });
+                };
+                reg_blocks(std::integral_constant<bool, !NOMFMA>{});
             });
             DS2_WTICK(4);
             const f32x4 sa = (accA[0] + accA[1]) + (accA[2] + accA[3]);
@@ -2400,7 +2414,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __
             // The stores of the PREVIOUS step are complete before this step's payload goes out (see CANARY_BITS): a wave's
             // vector-memory operations complete in issue order, this step's dh loads were issued behind those stores, and the
             // matrix phase has consumed them -- no wait of its own.  Ablation builds that can skip the loads or their validation wait.
-            if (FIRST || DS2_DBG(dbg, 2 | 2048)) wait_vmcnt0();
+            if constexpr (FIRST || NOVAL) wait_vmcnt0();
             DS2_WTICK(7);
             if (storer) {
                 const bool lose = DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
@@ -2411,16 +2425,23 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __
         const int aborted = abort_flag;                 // (issued here, consumed at the end of the step)
         const size_t og = of_g, on = of_n;
         // behind this step's payload: the next step's saved activations
-        if (s + 1 < T && !DS2_DBG(dbg, 8192)) early_loads(t, 1);
+        if (!NOPF && s + 1 < T) early_loads(t, 1);
         if (spec & (1 << 17)) wait_vmcnt0();            // self-timed: see spec_timing()
         sprev = scur;
         scur = (scur + 1) & (NSLOT - 1);
         DS2_WTICK(8);
         __syncthreads();
         DS2_WTICK(9);
-        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: one plain store per lane, off the critical path
-            if (gp == 3) ghn[on] = sv_g;
-            else G[og + (size_t)gp * H] = gp == 0 ? sv_r : (gp == 1 ? sv_z : sv_n);
+        {   // d(gi), d(gh_n) for the GEMMs that follow this launch, off the critical path: the quad's four units of this lane's
+            // plane (gp 0 .. 2: d(gi) of gates r, z, n; gp 3: d(gh_n)) gathered to its first lane -- one 16-byte store of a
+            // quarter of the lanes per wave and step instead of a 4-byte store of all of them
+            const float x = gp == 0 ? sv_r : (gp == 1 ? sv_z : (gp == 2 ? sv_n : sv_g));
+            f32x4 v;
+            v[0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x00, 0xF, 0xF, true));
+            v[1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x55, 0xF, 0xF, true));
+            v[2] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xAA, 0xF, 0xF, true));
+            v[3] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xFF, 0xF, 0xF, true));
+            if (gate_ok && u4 == 0) *reinterpret_cast<f32x4*>(gp == 3 ? ghn + on : G + og + (size_t)gp * H) = v;
         }
         of_g += dG;
         of_d += dD;
@@ -3447,7 +3468,7 @@ bool launch_fwd_persistent5(float* G, float* ghn, float* hout, const float* w_hh
     // planes, (8, 1, 6) -> (3, 1, 5): 2.27 / 2.16 -> 2.16 / 2.08 (without the planes: 2.15 at B = 10 either way); B = 12 (three full
     // quads) is the exception: 2.32 -> 2.48
     int d = 8, inc = 1, l2c = 6;
-    if (coef && B <= 11) d = 3, l2c = 5;
+    if (B <= 11) d = 3, l2c = 5;                    // (without the planes: 2.18 -> 2.15 at B = 10)
     if (const char* e = getenv("DS2_GRU_FWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
     hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, w_hh, coef, sync, ring, T, B, H, dbg, spec_timing(0, d, inc, l2c));
     return true;
@@ -3517,6 +3538,15 @@ bool launch_bwd_persistent6(float* G, float* ghn, const float* hout, const float
                             SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
     dim3 grid(ds2_cdiv(H, 4 * NRG), 2, NPART), block(NWP * 64);
     auto kern = &gru_bwd_persistent6_kernel<RPW, NRG, NPART>;
+#if defined(DS2_TIMING) || defined(DS2_FAULT_INJECT)
+    // the ablated instantiations bench.py's floor leg and the timing tools ask for (the forms of a B = 9 .. 12 step at H = 800)
+    if constexpr (RPW == 25 && NPART == 3 && (NRG == 5 || NRG == 7)) {
+        const int abl = dbg & (2 | 2048 | 4096 | 8192);
+        if (abl == (2 | 8192) || abl == 2) kern = &gru_bwd_persistent6_kernel<RPW, NRG, NPART, 2 | 8192>;
+        else if (abl == (2048 | 8192) || abl == 2048) kern = &gru_bwd_persistent6_kernel<RPW, NRG, NPART, 2048 | 8192>;
+        else if (abl == (4096 | 8192) || abl == 4096) kern = &gru_bwd_persistent6_kernel<RPW, NRG, NPART, 4096 | 8192>;
+    }
+#endif
     if (!grid_is_coresident(kern, grid, 0)) return false;
     // (first-attempt delay and adaptation policy of THIS kernel: DS2_GRU_BWD6_SPEC = "delay,inc,log2clean" for A/B runs)
     int d = 8, inc = 1, l2c = 5;

@@ -313,8 +313,10 @@ def recurrence_floor(bsz, t, hid, dev, spare_below):
     L.ds2_gru_sync_ws_bytes.restype = ctypes.c_size_t
     L.ds2_gru_sync_ws_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     vp, ci = ctypes.c_void_p, ctypes.c_int
-    L.ds2_gru_bidir_fwd_persistent.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp]
-    L.ds2_gru_bidir_bwd_persistent_ex.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    # the forms a training step launches: the forward pass with the coefficient planes as an output, the backward recurrence
+    # that hands off dh and takes them (include/ds2hip.h, ABI revision 402)
+    L.ds2_gru_bidir_fwd_persistent_ex.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+    L.ds2_gru_bidir_bwd_persistent_dh.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     ws = torch.zeros(L.ds2_gru_sync_ws_bytes(bsz, hid) // 4 + 64, dtype=torch.int32, device=dev)
     w = ((torch.rand(2, 3 * hid, hid, device=dev) * 2 - 1) / hid ** 0.5)
     wt = w.transpose(1, 2).contiguous()
@@ -322,6 +324,7 @@ def recurrence_floor(bsz, t, hid, dev, spare_below):
     ghn = torch.zeros(t, bsz, 2, hid, device=dev)
     hout = torch.zeros(2, t, bsz, hid, device=dev)
     d_out = 0.01 * torch.randn(t, bsz, hid, device=dev)
+    coef = torch.zeros(t, bsz, 2, 3 * hid, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     saved = {k: os.environ.get(k) for k in ('DS2_GRU_DBG',)}
 
@@ -334,11 +337,11 @@ def recurrence_floor(bsz, t, hid, dev, spare_below):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             if which == 'fwd':
-                rc = L.ds2_gru_bidir_fwd_persistent(g.data_ptr(), ghn.data_ptr(), hout.data_ptr(), w.data_ptr(), ws.data_ptr(),
-                                                    t, bsz, hid, st)
+                rc = L.ds2_gru_bidir_fwd_persistent_ex(g.data_ptr(), ghn.data_ptr(), hout.data_ptr(), w.data_ptr(), coef.data_ptr(),
+                                                       ws.data_ptr(), t, bsz, hid, st)
             else:
-                rc = L.ds2_gru_bidir_bwd_persistent_ex(g.data_ptr(), ghn.data_ptr(), hout.data_ptr(), d_out.data_ptr(),
-                                                       wt.data_ptr(), ws.data_ptr(), t, bsz, hid, spare, st)
+                rc = L.ds2_gru_bidir_bwd_persistent_dh(g.data_ptr(), ghn.data_ptr(), hout.data_ptr(), d_out.data_ptr(),
+                                                       wt.data_ptr(), coef.data_ptr(), ws.data_ptr(), t, bsz, hid, spare, st)
             e1.record()
             torch.cuda.synchronize()
             if rc != 0:
@@ -930,9 +933,9 @@ def main():
                                    'of the CUs it occupies, and the gate / reduction skeleton (DESIGN.md section 6).  achieved / '
                                    'peak / frac price the launch against the fp32-input MFMA roof (the contract\'s yardstick); '
                                    'floor_us_per_step is what the latency model allows',
-                     'kernel': 'the backward recurrence launch: gru_bwd_persistent5_kernel<5, 7> (28 units per workgroup) under the '
-                               'layers below the top one, <5, 5> (20 units) under the top layer (one launch = all T=%d steps of a '
-                               'BiGRU layer, both directions, B=%d)' % (t_mean, bsz),
+                     'kernel': 'the backward recurrence launch: gru_bwd_persistent6_kernel<25, 7> (d(h) hand-off, 28 units per workgroup) '
+                               'under the layers below the top one, <25, 5> (20 units) under the top layer (one launch = all T=%d steps '
+                               'of a BiGRU layer, both directions, B=%d)' % (t_mean, bsz),
                      'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 5), 'traffic': traffic, 'traffic_source': traffic_src,
                      'traffic_algorithmic': traffic_alg,
