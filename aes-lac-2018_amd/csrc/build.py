@@ -163,9 +163,40 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_tuning(force=False):
+    """libds2hip_tuning.so: EVERY source compiled with -DDS2_TUNING=1, the build in which ds2_tune_env (ds2_common.h) reads the
+    tuning knobs the release library ignores (tile widths, split-K targets, hand-off timing policies, forms no default dispatch
+    reaches).  For tools/ sweeps: `DS2_LIB_VARIANT=tuning python tools/...`.  Objects under csrc/build/tuning/."""
+    out_dir = os.path.join(OBJ, 'tuning')
+    os.makedirs(out_dir, exist_ok=True)
+    _stamp_build_id()
+    srcs = sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
+    deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')] + [os.path.join(ROOT, 'include', 'ds2hip.h')]
+    jobs, objs = [], []
+    for s in srcs:
+        src, obj = os.path.join(HERE, s), os.path.join(out_dir, s[:-4] + '.o')
+        objs.append(obj)
+        if force or _newer(src, obj, deps):
+            jobs.append([HIPCC] + FLAGS + ['-DDS2_TUNING=1', '-c', src, '-o', obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s\n%s' % (' '.join(cmd), r.stdout, r.stderr))
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    out = os.path.join(PKG, 'ds2hip', 'libds2hip_tuning.so')
+    if jobs or not os.path.exists(out):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+    return out
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))
-    if '--variant' in sys.argv:
+    if '--variant' in sys.argv and sys.argv[sys.argv.index('--variant') + 1] == 'tuning':
+        print(build_tuning(force='--force' in sys.argv))
+    elif '--variant' in sys.argv:
         name = sys.argv[sys.argv.index('--variant') + 1]
         flags = {'timing': ['-DDS2_TIMING=1']}.get(name)
         if flags is None:                      # e.g. --variant spec_12_4 -> -DDS2_SPEC_DELAY=12 -DDS2_SPEC_BACKOFF=4

@@ -667,9 +667,9 @@ extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, con
         const long waves = (long)B * ds2_cdiv(tout, 32 * nt) * g.fout;
         return (double)((waves + 1023) / 1024) * nt;
     };
-    const bool narrow = getenv("DS2_CONV_NT") ? atoi(getenv("DS2_CONV_NT")) == 1 : rounds(1) < rounds(2);
+    const bool narrow = ds2_tune_env("DS2_CONV_NT") ? atoi(ds2_tune_env("DS2_CONV_NT")) == 1 : rounds(1) < rounds(2);
     // conv2: 64 time steps per wave always (half the filter traffic per output), the K split below supplies the waves
-    const int nt = (which == 2 && !getenv("DS2_CONV_NT")) ? 2 : (narrow ? 1 : 2);
+    const int nt = (which == 2 && !ds2_tune_env("DS2_CONV_NT")) ? 2 : (narrow ? 1 : 2);
     const int ttiles = ds2_cdiv(tout, 32 * nt);
     const long ntiles = (long)B * ttiles * g.fout;
     // K split inside the workgroup (two waves per tile) while the tiles alone give fewer than ~4 waves per SIMD: more waves
@@ -677,7 +677,7 @@ extern "C" int ds2_conv_fwd(int which, const float* in, const float* weight, con
     // (measured, B = 10, conv2 forward, ms: T_in = 300 0.39 -> 0.27 (KS 4), 500 0.41 -> 0.35 (KS 2), 830 0.56 -> 0.51 (KS 2),
     // 1501 0.85 -> 0.81 (KS 2); conv1's 41-row tiles are too short to split)
     int ks = which == 1 ? 1 : (ntiles < 700 ? 4 : (ntiles < 4096 ? 2 : 1));
-    if (getenv("DS2_CONV_KS")) ks = atoi(getenv("DS2_CONV_KS")) == 4 ? 4 : (atoi(getenv("DS2_CONV_KS")) == 2 ? 2 : 1);
+    if (ds2_tune_env("DS2_CONV_KS")) ks = atoi(ds2_tune_env("DS2_CONV_KS")) == 4 ? 4 : (atoi(ds2_tune_env("DS2_CONV_KS")) == 2 ? 2 : 1);
     dim3 grid((unsigned)((ntiles * ks + 3) / 4)), block(256);
 #define DS2_CONV_FWD_GO(C, KF_, SF_, ST_, P_, N_)                                                                       \
     do {                                                                                                                \
@@ -726,15 +726,15 @@ extern "C" int ds2_conv2_dgrad(const float* d_out, const float* weight, int B, i
         const long waves = (long)B * ds2_cdiv(T1, 32 * nt) * 61;
         return (double)((waves + 1023) / 1024) * nt;
     };
-    const bool narrow = getenv("DS2_CONV_NT") ? atoi(getenv("DS2_CONV_NT")) == 1 : rounds(1) < rounds(2);
-    const int nt = getenv("DS2_CONV_NT") ? (narrow ? 1 : 2) : 2;
+    const bool narrow = ds2_tune_env("DS2_CONV_NT") ? atoi(ds2_tune_env("DS2_CONV_NT")) == 1 : rounds(1) < rounds(2);
+    const int nt = ds2_tune_env("DS2_CONV_NT") ? (narrow ? 1 : 2) : 2;
     const int ttiles = ds2_cdiv(T1, 32 * nt);
     const long ntiles = (long)B * ttiles * 61;
     // K split inside the workgroup: as in ds2_conv_fwd.  Measured, B = 10, ms, 32-step tiles unsplit -> 64-step tiles with
     // four K shares: T_in = 300 0.28 -> 0.25, 830 0.64 -> 0.48, 1100 0.84 -> 0.61, 1501 1.05 -> 0.77
     // (B = 32 / 64 at T_in = 1000: 2.09 -> 1.56 / 3.93 -> 3.06)
     int ks = 4;
-    if (getenv("DS2_CONV_KS")) ks = atoi(getenv("DS2_CONV_KS")) == 4 ? 4 : (atoi(getenv("DS2_CONV_KS")) == 2 ? 2 : 1);
+    if (ds2_tune_env("DS2_CONV_KS")) ks = atoi(ds2_tune_env("DS2_CONV_KS")) == 4 ? 4 : (atoi(ds2_tune_env("DS2_CONV_KS")) == 2 ? 2 : 1);
     const dim3 grid((unsigned)((ntiles * ks + 3) / 4));
 #define DS2_DGRAD_GO(N_, K_)                                                                                             \
     hipLaunchKernelGGL((conv2_dgrad_kernel<21, N_, K_>), grid, dim3(256), 0, st, d_out, wt_ws, B, 61, T1, 21, T, ttiles, d_in)
@@ -771,7 +771,7 @@ extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, in
     const bool split_form = lds_form && !(getenv("DS2_CONV_WGRAD_BF16") && getenv("DS2_CONV_WGRAD_BF16")[0] == '0');
     if (split_form) {
         int split = which == 1 ? 256 : 105;              // the LDS form's workgroup counts (below)
-        const char* e = getenv(which == 1 ? "DS2_CONV1_WGRAD_SPLIT" : "DS2_CONV_WGRAD_SPLIT");
+        const char* e = ds2_tune_env(which == 1 ? "DS2_CONV1_WGRAD_SPLIT" : "DS2_CONV_WGRAD_SPLIT");
         if (e) split = atoi(e);
         if (split > rows) split = rows;
         if (split < 1) split = 1;
@@ -784,7 +784,7 @@ extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, in
     } else if (which == 1 && lds_form) {
         // conv1 through LDS (round 4): 4 groups of 128 taps x up to 256 row splits ~ 1000 workgroups, ~4 per CU
         int split = 256;
-        if (getenv("DS2_CONV1_WGRAD_SPLIT")) split = atoi(getenv("DS2_CONV1_WGRAD_SPLIT"));
+        if (ds2_tune_env("DS2_CONV1_WGRAD_SPLIT")) split = atoi(ds2_tune_env("DS2_CONV1_WGRAD_SPLIT"));
         if (split > rows) split = rows;
         if (split < 1) split = 1;
         hipLaunchKernelGGL((conv_wgrad_lds_kernel<1, 41, 2, 2, 10>), dim3(ds2_cdiv(ntot, 128), split), block, 0, st, in, d_out, B,
@@ -798,7 +798,7 @@ extern "C" int ds2_conv_wgrad(int which, const float* in, const float* d_out, in
         // 13 ... 53 splits: 0.42 - 0.49 at B = 10).  DS2_CONV_WGRAD_LDS = 0: the direct kernel, for A/B timing and tests
         const int ngroups = ds2_cdiv(ntot, 128);
         int split = 105;
-        if (getenv("DS2_CONV_WGRAD_SPLIT")) split = atoi(getenv("DS2_CONV_WGRAD_SPLIT"));
+        if (ds2_tune_env("DS2_CONV_WGRAD_SPLIT")) split = atoi(ds2_tune_env("DS2_CONV_WGRAD_SPLIT"));
         if (split > rows) split = rows;
         if (split < 1) split = 1;
         hipLaunchKernelGGL((conv_wgrad_lds_kernel<32, 21, 2, 1, 0>), dim3(ngroups, split), block, 0, st, in, d_out, B, g.fin, tin,

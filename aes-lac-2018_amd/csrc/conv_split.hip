@@ -313,8 +313,8 @@ struct GatherPlan {
 // (the forward pass is never split over K: float atomics would make its output -- and with it every activation, eval included
 // -- vary in the last bits from run to run)
 GatherPlan plan_gather(int M, int nstep, bool may_split) {
-    static const int force_ks = getenv("DS2_CONV_SPLIT_KS") ? atoi(getenv("DS2_CONV_SPLIT_KS")) : 0;
-    static const int force_nt = getenv("DS2_CONV_SPLIT_NT") ? atoi(getenv("DS2_CONV_SPLIT_NT")) : 0;
+    static const int force_ks = ds2_tune_env("DS2_CONV_SPLIT_KS") ? atoi(ds2_tune_env("DS2_CONV_SPLIT_KS")) : 0;
+    static const int force_nt = ds2_tune_env("DS2_CONV_SPLIT_NT") ? atoi(ds2_tune_env("DS2_CONV_SPLIT_NT")) : 0;
     GatherPlan p;
     const int waves64 = ds2_cdiv(M, 64);
     p.nt = force_nt > 0 ? force_nt : (waves64 >= 1536 ? 2 : 1);   // (B = 10: T_in 500 0.217 / 0.252 ms with 32 / 64, 830 a tie, 1100 0.469 / 0.403)
@@ -422,7 +422,7 @@ int ds2_conv2_dgrad_split(const float* d_out, const float* weight, int B, int t1
     // kernel) 15.24-15.32, never 15.26-15.28, always 15.15-15.18; thresholds 0 / 1000 / 2000 equal (15.02-15.08 on another
     // box): 1000.
     const char* on = getenv("DS2_CONV_SPLIT_DGRAD");
-    static const int dgrad_min = getenv("DS2_CONV_SPLIT_DGRAD_MIN") ? atoi(getenv("DS2_CONV_SPLIT_DGRAD_MIN")) : 1000;
+    static const int dgrad_min = ds2_tune_env("DS2_CONV_SPLIT_DGRAD_MIN") ? atoi(ds2_tune_env("DS2_CONV_SPLIT_DGRAD_MIN")) : 1000;
     if (on ? on[0] != '1' : (long)B * t1 < dgrad_min) return 1;
     const int T = t1 - 10, TP = T + 20;
     const unsigned long long a_bytes = 4ull * B * 32 * 41 * TP, o_elems = 1ull * B * 32 * 61 * t1;

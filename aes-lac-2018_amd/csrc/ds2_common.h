@@ -38,6 +38,19 @@ int ds2_conv2_fwd_split(const float* in, const float* weight, const float* bias,
 
 static inline int ds2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Environment switches come in two kinds.  SELECTION switches (a kernel family or form that tests and documented A/B runs pick:
+// DS2_GRU_FWD / _BWD / _FWD_WIDE / _P2_BF16 / _P2_BF16_BWD, DS2_CONV_SPLIT / _SPLIT_DGRAD / _WGRAD_LDS / _WGRAD_BF16 /
+// _DGRAD_ROWS / _DGRAD_MERGE, DS2_GEMM_SPLIT) are read with getenv by every build.  TUNING knobs (tile widths, split-K targets,
+// hand-off timing policies, forms no default dispatch reaches: their measured best IS the default, DESIGN.md has the sweeps)
+// are read with ds2_tune_env, which is getenv only in the TUNING builds -- `python csrc/build.py --variant tuning`
+// (-DDS2_TUNING=1 on every file) and the timing / fault-injection / ablation variants -- and nothing in the release library.
+#if defined(DS2_TUNING) || defined(DS2_TIMING) || defined(DS2_FAULT_INJECT) || defined(DS2_ABLATION_BUILD)
+#include <stdlib.h>
+static inline const char* ds2_tune_env(const char* name) { return getenv(name); }
+#else
+static inline const char* ds2_tune_env(const char*) { return nullptr; }
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -726,7 +726,7 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
         if ((tiles < 512 && K >= 512) || (tiles < 2048 && K >= 2048)) {
             // (the split-operand kernels run a work item ~1.6x faster, so prologue, epilogue and atomics weigh more: stand-alone
             // dX 242 -> 213 us and dW_ih 242 -> 226 us with ~1024 items instead of ~8192, whole step -0.9 %)
-            static const int env_target = getenv("DS2_GEMM_SPLIT_TARGET") ? atoi(getenv("DS2_GEMM_SPLIT_TARGET")) : 0;
+            static const int env_target = ds2_tune_env("DS2_GEMM_SPLIT_TARGET") ? atoi(ds2_tune_env("DS2_GEMM_SPLIT_TARGET")) : 0;
             const int target = env_target > 0 ? env_target : (gemm_split_mode() != 0 ? 1024 : 8192);
             split_k = target / tiles;
             const int max_split = K / 320 > 1 ? K / 320 : 1;
@@ -772,7 +772,7 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
     }
     const bool vec0 = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)B & 15) == 0) &&
                       ((!AK && !BKc) || K % 4 == 0);
-    static const bool v2_on = !(getenv("DS2_GEMM_V2") && getenv("DS2_GEMM_V2")[0] == '0');    // A/B timing switch
+    static const bool v2_on = !(ds2_tune_env("DS2_GEMM_V2") && ds2_tune_env("DS2_GEMM_V2")[0] == '0');    // A/B timing switch
     // (a 256 x 128 kernel with three LDS slab buffers for this family -- gemm_f32_v3_kernel, round 2: 134 against 124 TFLOP/s on
     // 4096^3, behind the stream-K kernel on the model's one-round shapes -- went when the split-operand family became the
     // default; removed in round 5)
@@ -899,7 +899,7 @@ extern "C" int ds2_gemm_f32_tn_group(int count, const float* const* A_host, cons
     // split K so that the launch has ~3 work items per resident slot (the rule of the single launch), >= 320 k per item
     int split_k = 1;
     if (tot_tiles < 512 && K >= 512) {
-        static const int env_target = getenv("DS2_GEMM_GROUP_TARGET") ? atoi(getenv("DS2_GEMM_GROUP_TARGET")) : 0;
+        static const int env_target = ds2_tune_env("DS2_GEMM_GROUP_TARGET") ? atoi(ds2_tune_env("DS2_GEMM_GROUP_TARGET")) : 0;
         const int target = env_target > 0 ? env_target : (gemm_split_mode() != 0 ? 1024 : 3072);
         split_k = target / tot_tiles;
         const int max_split = K / 320 > 1 ? K / 320 : 1;

@@ -3235,17 +3235,17 @@ __global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent5_kernel(float* __
 // older kernels (B = 4 / 8) lose with the slow decay (forward 1.65 -> 1.75 / backward 2.32 -> 2.50) and keep (1, 2).
 inline int spec_timing(int bwd, int def_delay = -1, int def_inc = 1, int def_log2clean = 2) {
     int delay = def_delay >= 0 ? def_delay : (bwd ? 14 : 10), backoff = 2;
-    const char* e = getenv(bwd ? "DS2_GRU_SPEC_BWD" : "DS2_GRU_SPEC_FWD");
+    const char* e = ds2_tune_env(bwd ? "DS2_GRU_SPEC_BWD" : "DS2_GRU_SPEC_FWD");
     if (e) {
         delay = atoi(e);
         const char* c = strchr(e, ',');
         if (c) backoff = atoi(c + 1);
     }
     int adaptive = 1;                                  // bit 0: adapt the sleep count; bit 1: self-timed (wait for the own stores' acks)
-    const char* a = getenv("DS2_GRU_SPEC_ADAPT");
+    const char* a = ds2_tune_env("DS2_GRU_SPEC_ADAPT");
     if (a) adaptive = atoi(a);
     int inc = def_inc, log2clean = def_log2clean;      // adaptation: +inc after a step with a re-load, -1 after 2^log2clean clean ones
-    const char* pol = getenv("DS2_GRU_SPEC_POLICY");
+    const char* pol = ds2_tune_env("DS2_GRU_SPEC_POLICY");
     if (pol) {
         inc = atoi(pol);
         const char* c = strchr(pol, ',');
@@ -3402,7 +3402,7 @@ inline int kbal_kpl(int H, int rows_per_part, int proto) {
     // whose hand-off data lands first ran under the wait for the rest.  With the saved-activation loads prefetched, the
     // compiler's stray vmcnt(0) gone and staged consumption (all round 4) the matrix pipe is on the chain: 2.73 -> 2.66
     // (2.67-2.72 -> 2.61 with the 2-sleep gap between fragment loads) / 2.30 -> 2.30 (2.28 -> 2.25).
-    const char* e = getenv("DS2_GRU_FWD_KBAL");
+    const char* e = ds2_tune_env("DS2_GRU_FWD_KBAL");
     if (e && e[0] == '0') return 0;
     if (H % 32 != 0 || rows_per_part > 4 || proto == 0) return 0;
     const int kpl = H / 32, ch = (kpl + 3) / 4, last = kpl - 3 * ch;
@@ -3430,7 +3430,7 @@ bool launch_fwd_persistent4(float* G, float* ghn, float* hout, const float* w_hh
             // (this kernel's hand-off timing: DS2_GRU_FWD4_SPEC = "delay,inc,log2clean" for A/B runs)
             // (measured, us per forward step, (10, 1, 2) -> (8, 1, 5): B = 8 2.15 -> 2.05, B = 6 1.97 -> 1.94, B = 5 1.99 -> 1.94)
             int d = 8, inc = 1, l2c = 5;
-            if (const char* e = getenv("DS2_GRU_FWD4_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
+            if (const char* e = ds2_tune_env("DS2_GRU_FWD4_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
             hipLaunchKernelGGL(kern, grid, block, lds, st, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, spec_timing(0, d, inc, l2c));
             return true;
         }
@@ -3469,7 +3469,7 @@ bool launch_fwd_persistent5(float* G, float* ghn, float* hout, const float* w_hh
     // quads) is the exception: 2.32 -> 2.48
     int d = 8, inc = 1, l2c = 6;
     if (B <= 11) d = 3, l2c = 5;                    // (without the planes: 2.18 -> 2.15 at B = 10)
-    if (const char* e = getenv("DS2_GRU_FWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
+    if (const char* e = ds2_tune_env("DS2_GRU_FWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
     hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, w_hh, coef, sync, ring, T, B, H, dbg, spec_timing(0, d, inc, l2c));
     return true;
 }
@@ -3514,7 +3514,7 @@ bool launch_bwd_persistent5(float* G, float* ghn, const float* hout, const float
     // (measured at B = 10, us per step, (14, 1, 2) -> (10, 1, 4): 28 units 2.95 -> 2.86, 24 units 2.74 -> 2.65; 20 units
     // 2.67-2.69 -> 2.54, and 2.51 with (10, 1, 5) -- with that the broadcast deal beats the 16-k-blocks deal's 2.61-2.64 there too)
     int d = NRG == 4 ? 8 : 10, inc = 1, l2c = NRG <= 5 ? 5 : 4;
-    if (const char* e = getenv("DS2_GRU_BWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
+    if (const char* e = ds2_tune_env("DS2_GRU_BWD5_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
     const int spec = spec_timing(1, d, inc, l2c);
 #define DS2_BWD5_CASE(K)                                                                                         \
     case K:                                                                                                      \
@@ -3550,7 +3550,7 @@ bool launch_bwd_persistent6(float* G, float* ghn, const float* hout, const float
     if (!grid_is_coresident(kern, grid, 0)) return false;
     // (first-attempt delay and adaptation policy of THIS kernel: DS2_GRU_BWD6_SPEC = "delay,inc,log2clean" for A/B runs)
     int d = 8, inc = 1, l2c = 5;
-    if (const char* e = getenv("DS2_GRU_BWD6_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
+    if (const char* e = ds2_tune_env("DS2_GRU_BWD6_SPEC")) sscanf(e, "%d,%d,%d", &d, &inc, &l2c);
     hipLaunchKernelGGL(kern, grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, coef, sync, ring, T, B, H, dbg,
                        spec_timing(1, d, inc, l2c));
     return true;
@@ -3613,7 +3613,7 @@ inline bool persistent_ok(int B, int H) {
 // canaries double the write-through stores and the drained protocol is faster (B = 32 backward: 6.4 vs 6.8 us, B = 64:
 // 11.3 vs 12.8).  DS2_GRU_PROTO = 0 / 2 forces one (A/B timing).
 inline int handoff_protocol(int rows_per_part) {
-    const char* e = getenv("DS2_GRU_PROTO");
+    const char* e = ds2_tune_env("DS2_GRU_PROTO");
     if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
     return rows_per_part <= 4 ? 2 : 0;
 }
@@ -3697,7 +3697,7 @@ extern "C" int ds2_gru_bidir_fwd_persistent_ex(float* G, float* ghn, float* hout
     const bool ngi_ok = ds2_cdiv(ds2_cdiv(H, 64), NWP) <= 3;
     int parts = B <= 4 ? 1 : (B <= 8 ? 2 : 3);
     {
-        const char* split = getenv("DS2_GRU_FWD_SPLIT");
+        const char* split = ds2_tune_env("DS2_GRU_FWD_SPLIT");
         if (split && split[0] >= '1' && split[0] <= '3') parts = split[0] - '0';
         if (parts > B) parts = B;
         // gate-role capacity: two passes of 512 / (4 * 8 parts) batch rows per workgroup; all workgroups co-resident
@@ -3718,7 +3718,7 @@ extern "C" int ds2_gru_bidir_fwd_persistent_ex(float* G, float* ghn, float* hout
         if (parts == 3 && !two && proto != 0 && (wide ? wide[0] == '1' : true) && H % 4 == 0 &&
             6 * ds2_cdiv(H, 20) <= max_persistent_wgs() && 6 * ds2_cdiv(H, 20) > 6 * ds2_cdiv(H, 24)) {
             // the row deal where it is built (H = 800: 100 columns per wave); DS2_GRU_FWD_ROWS = 0: the k-balanced deal (A/B timing)
-            const char* rows = getenv("DS2_GRU_FWD_ROWS");
+            const char* rows = ds2_tune_env("DS2_GRU_FWD_ROWS");
             if (H == 800 && bper <= 4 && !(rows && rows[0] == '0'))
             {
                 ok = launch_fwd_persistent5<100>(G, ghn, hout, w_hh, coef, sync, ring, T, B, H, dbg, st);
@@ -3737,7 +3737,7 @@ extern "C" int ds2_gru_bidir_fwd_persistent_ex(float* G, float* ghn, float* hout
     }
     // (round 4, us per step at H = 800: the split-operand two-part form costs 3.32-3.36 whatever B <= 32 is; the whole-batch
     // 16x16x4 form 3.63 at B = 16 -- so the split form takes over as soon as the 4x4x1 forms end, at B = 13)
-    else if ((getenv("DS2_GRU_FWD_P2") ? getenv("DS2_GRU_FWD_P2")[0] == '1' : B >= (p2_bf16(H) ? 13 : 17)) && B >= 2 && H % 16 == 0)
+    else if ((ds2_tune_env("DS2_GRU_FWD_P2") ? ds2_tune_env("DS2_GRU_FWD_P2")[0] == '1' : B >= (p2_bf16(H) ? 13 : 17)) && B >= 2 && H % 16 == 0)
         ok = p2_bf16(H) ? ((B + 1) / 2 <= 16 ? launch_fwd_persistent_p2b<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
                                              : launch_fwd_persistent_p2b<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
                         : ((B + 1) / 2 <= 16 ? launch_fwd_persistent_p2<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
@@ -3789,7 +3789,7 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
     // 7.0 / 12.3, see gru_bwd_persistent_p2_kernel).  DS2_GRU_BWD = "4" / "16" forces a family, DS2_GRU_BWD_P2 = 0 / 1 the
     // two-part 16x16x4 form off / on (A/B timing).
     const char* form = getenv("DS2_GRU_BWD");
-    const char* p2e = getenv("DS2_GRU_BWD_P2");
+    const char* p2e = ds2_tune_env("DS2_GRU_BWD_P2");
     const bool p2 = (p2e ? p2e[0] == '1' : (B >= 17 && !(form && form[0] == '4'))) && B >= 2 && H % 16 == 0;
     const bool use4 = !p2 && (form ? form[0] == '4' : true);
     // Batch parts (1, 2 or 3: 8, 16 or 24 units per workgroup) by the fitted cost model; measured, H = 800, us per step,
@@ -3807,7 +3807,7 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
                 parts = p;
             }
         }
-        const char* split = getenv("DS2_GRU_BWD_SPLIT");
+        const char* split = ds2_tune_env("DS2_GRU_BWD_SPLIT");
         if (split && split[0] >= '1' && split[0] <= '3' && (split[0] - '0') <= B) parts = split[0] - '0';
     }
     const bool ngi_ok = ds2_cdiv(ds2_cdiv(3 * H, 64), NWP) <= 5;
@@ -3833,7 +3833,7 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
         // units per workgroup by the CUs to leave free (see above); DS2_GRU_BWD_WIDE = 0 / 1 / 2 forces 24 / 28 / 20 (A/B timing)
         const int cus = device_cus();
         int want = spare_cus < 0 ? 52 : spare_cus;
-        const char* w = getenv("DS2_GRU_BWD_WIDE");
+        const char* w = ds2_tune_env("DS2_GRU_BWD_WIDE");
         if (w && w[0] >= '0' && w[0] <= '2') want = w[0] == '0' ? 52 : (w[0] == '1' ? 82 : 0);
         const int g20 = 6 * ds2_cdiv(H, 20), g24 = 6 * ds2_cdiv(H, 24), g28 = 6 * ds2_cdiv(H, 28);
         // the broadcast deal (gru_bwd_persistent5_kernel): H is a multiple of 16 and a part is one batch quad here.  Measured
@@ -3903,7 +3903,7 @@ extern "C" int ds2_gru_bidir_bwd_persistent_dh(float* G, float* ghn, const float
     if (B >= 9) {                                       // three parts of one batch quad: units per workgroup by the CUs to leave free
         const int cus = device_cus();
         int want = spare_cus < 0 ? 52 : spare_cus;
-        const char* w = getenv("DS2_GRU_BWD_WIDE");
+        const char* w = ds2_tune_env("DS2_GRU_BWD_WIDE");
         if (w && w[0] >= '0' && w[0] <= '2') want = w[0] == '0' ? 52 : (w[0] == '1' ? 82 : 0);
         const int g20 = 6 * ds2_cdiv(H, 20), g24 = 6 * ds2_cdiv(H, 24), g28 = 6 * ds2_cdiv(H, 28);
         if (H == 800) {

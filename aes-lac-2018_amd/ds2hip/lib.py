@@ -11,6 +11,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libds2hip.so')
+# DS2_LIB_VARIANT=<name>: load libds2hip_<name>.so instead -- the tools' way to a variant build (csrc/build.py --variant:
+# `tuning` = the library that reads the tuning knobs, `timing`, `faultinject`, ablations); never set by the product or the tests
+if os.environ.get('DS2_LIB_VARIANT'):
+    LIB_PATH = os.path.join(_HERE, 'libds2hip_%s.so' % os.environ['DS2_LIB_VARIANT'])
 
 _I = ctypes.c_int
 _F = ctypes.c_float

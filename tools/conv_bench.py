@@ -1,4 +1,6 @@
 """Stand-alone timing of the conv kernels at the bench shape (B=10, T_in ~ 830)."""
+# (the knobs this tool sweeps are TUNING knobs: read only by `python aes-lac-2018_amd/csrc/build.py --variant tuning`,
+# i.e. run it with DS2_LIB_VARIANT=tuning -- the release library ignores them; csrc/ds2_common.h: ds2_tune_env)
 import os, sys
 sys.path.insert(0, 'aes-lac-2018_amd'); sys.path.insert(0, '.')
 import torch, numpy as np

@@ -1,5 +1,7 @@
 """d(h) hand-off backward recurrence (gru_bwd_persistent6_kernel) against the launch-per-step kernels and the d(gh) hand-off
 form, and its time per step: python tools/gru_dh_check.py [BSZ ...]   (TSTEPS, SPARE_CUS, DS2_GRU_BWD6_SPEC from the env)"""
+# (the knobs this tool sweeps are TUNING knobs: read only by `python aes-lac-2018_amd/csrc/build.py --variant tuning`,
+# i.e. run it with DS2_LIB_VARIANT=tuning -- the release library ignores them; csrc/ds2_common.h: ds2_tune_env)
 import os, sys
 _ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, os.path.join(_ROOT, 'aes-lac-2018_amd')); sys.path.insert(0, _ROOT)

@@ -6,6 +6,8 @@
 DS2_GRU_DBG bits (results are WRONG when set): 1 = do not wait for arrivals, 2 = skip the hand-off loads + MFMAs,
 4 = skip the store drain.  Extra env (DS2_GRU_FWD_SPLIT, ...) passes through.
 """
+# (the knobs this tool sweeps are TUNING knobs: read only by `python aes-lac-2018_amd/csrc/build.py --variant tuning`,
+# i.e. run it with DS2_LIB_VARIANT=tuning -- the release library ignores them; csrc/ds2_common.h: ds2_tune_env)
 import os
 import sys
 

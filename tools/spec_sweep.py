@@ -1,4 +1,6 @@
 """Sweep the speculative hand-off's first-attempt delay / re-load backoff (DS2_GRU_SPEC_FWD / DS2_GRU_SPEC_BWD, read per launch)."""
+# (the knobs this tool sweeps are TUNING knobs: read only by `python aes-lac-2018_amd/csrc/build.py --variant tuning`,
+# i.e. run it with DS2_LIB_VARIANT=tuning -- the release library ignores them; csrc/ds2_common.h: ds2_tune_env)
 import os, sys
 os.environ.setdefault('DS2_SWEEP_LIB', '')
 sys.argv = sys.argv[:1]
