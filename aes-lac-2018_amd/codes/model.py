@@ -158,7 +158,10 @@ class DeepSpeech(nn.Module):
         feat = (feat - 41) // 2 + 1
         feat = (feat - 21) // 2 + 1
         if window_size != 320:
-            raise NotImplementedError('conv kernels are specialised for 161 frequency bins (window_size=320)')
+            raise NotImplementedError('window_size=%r: the HIP conv / BatchNorm-layout / STFT kernels are specialised for 161 '
+                                      'frequency bins (window_size=320, every shipped config); the reference accepts any '
+                                      'window (codes/model.py:124,148-151) -- README.md "What the drop-in does not cover"'
+                                      % (window_size,))
         self._rnn_input_size = 32 * feat
         rnns = [('0', BatchRNN(self._rnn_input_size, rnn_hidden_size, batch_norm=False))]
         for i in range(num_rnn_layers - 1):

@@ -48,6 +48,14 @@ def get_model(model_dict):
     if isinstance(model_dict.langs, (tuple, set, list)) and len(model_dict.langs) > 1:
         raise NotImplementedError('multi-task models are out of scope (SURVEY.md section 2 row 1)')
     params = dict(model_dict.get('params', {}) or {})
+    # The drop-in covers ONE frontend geometry: 320-sample windows (20 ms at 16 kHz, 161 frequency bins) -- what every shipped
+    # config and the reference's released checkpoints use.  The reference derives the model's input width for any window
+    # (codes/model.py:124,148-151); the HIP conv, BatchNorm-layout and STFT kernels are specialised for 161 bins, so a config
+    # that asks for another one is refused HERE, when it is loaded, with the reason -- not later inside the constructor.
+    if int(params.get('window_size', 320)) != 320:
+        raise ValueError('model.params.window_size = %r: this MI355X path implements window_size = 320 only (161 frequency '
+                         'bins; conv / BatchNorm / STFT kernels are specialised for it) -- see README.md "What the drop-in '
+                         'does not cover"' % (params['window_size'],))
     params.setdefault('num_classes', NUM_CLASSES[model_dict.langs[0]])
     model_dict['params'] = params
     return DeepSpeech(**params)

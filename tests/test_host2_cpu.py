@@ -582,6 +582,16 @@ def test_bench_gpus_n_end_to_end_with_a_stub_launcher(tmp_path):
     assert r.stdout.decode().strip() == ''                                # no JSON line from a failed run
 
 
+def test_quoted_kernel_averages_come_from_the_csvs():
+    """profiles/README.md and DESIGN.md section 6 quote per-kernel averages of the round's profiled runs: the blocks are written
+    by tools/profiles_readme.py FROM profiles/r06_bench_*_kernel_stats.csv and must equal what the CSVs give (round 5's prose had
+    drifted from its files)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'profiles_readme.py'), '--check'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def _fake_node(tmp_path, gpu_numa=(0, 0, 0, 0, 1, 1, 1, 1), cpus_per_node=16):
     """A sysfs tree of a two-socket node: KFD nodes 0-1 are the CPUs, 2.. the GPUs (one PCI bus each)."""
     root = tmp_path / 'sysfs'

@@ -103,6 +103,17 @@ def test_constructor_surface():
         DeepSpeech(bidirectional=False)
     with pytest.raises(NotImplementedError):
         DeepSpeech(rnn_type='lstm')
+    # window_size: the reference derives rnn_input_size for any window (codes/model.py:124,148-151); this path is fenced to 320
+    # -- in the constructor, and already when a config is loaded (get_model), each time with the reason
+    with pytest.raises(NotImplementedError, match='window_size=400'):
+        DeepSpeech(window_size=400)
+    from codes.utils import training_utils as tu
+    from codes.utils.io_utils import AttrDict
+    cfg = AttrDict({'langs': ['en'], 'params': {'window_size': 400, 'rnn_hidden_size': 32, 'num_rnn_layers': 2}})
+    with pytest.raises(ValueError, match='window_size = 320 only'):
+        tu.get_model(cfg)
+    cfg = AttrDict({'langs': ['en'], 'params': {'window_size': 320, 'rnn_hidden_size': 32, 'num_rnn_layers': 2}})
+    assert tu.get_model(cfg)._rnn_input_size == 672
 
 
 def test_flat_parameter_views():
