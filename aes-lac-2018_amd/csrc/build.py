@@ -169,14 +169,14 @@ def build_tuning(force=False):
     reaches).  For tools/ sweeps: `DS2_LIB_VARIANT=tuning python tools/...`.  Objects under csrc/build/tuning/."""
     out_dir = os.path.join(OBJ, 'tuning')
     os.makedirs(out_dir, exist_ok=True)
-    _stamp_build_id()
+    id_header = _stamp_build_id()
     srcs = sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
     deps = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')] + [os.path.join(ROOT, 'include', 'ds2hip.h')]
     jobs, objs = [], []
     for s in srcs:
         src, obj = os.path.join(HERE, s), os.path.join(out_dir, s[:-4] + '.o')
         objs.append(obj)
-        if force or _newer(src, obj, deps):
+        if force or _newer(src, obj, deps + ([id_header] if s == 'api.hip' else [])):
             jobs.append([HIPCC] + FLAGS + ['-DDS2_TUNING=1', '-c', src, '-o', obj])
 
     def run(cmd):
