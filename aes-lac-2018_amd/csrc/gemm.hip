@@ -675,126 +675,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x_tn_group_kernel(GemmGroup g
                                          k_per_split, 1, g.a_bytes[p], g.b_bytes[p], blockIdx.x, blockIdx.y);
 }
 
-// ----------------------------------------------------------------------------------------------------------
-// The same GEMM on a 256 x 128 tile with ONE wave per SIMD (round 6): four waves in 2 x 2, 128 x 64
-// outputs each = 4 x 2 accumulator tiles x (hi + lo) = 256 accumulator registers (the matrix instruction takes them from the
-// AGPR half of the 512 a single wave per SIMD may hold).  Per 16-deep slab a wave reads 18 fragments for 48 MFMAs (the
-// 128 x 128 kernel: 12 for 24), a workgroup loads and splits 24.6 KB for 192 MFMAs (16 KB for 96): LDS operand reads per MFMA
-// x 0.75, global loads / split arithmetic / LDS stores per MFMA x 0.75.  LDS: [buffer 2][A rows 0-127 | A rows 128-255 | B]
-// images of split_bf16.h's layout = 86 KB (dynamic).  Columns past N are skipped per (wave, column tile): the last column tile
-// of N = 800 (32 columns) costs half a tile's time, not a whole one.
-// ----------------------------------------------------------------------------------------------------------
-constexpr int BM2 = 256;
-constexpr int BIG_LDS_BYTES = 2 * 3 * SPLIT_TILE_BYTES;
-template <bool A_KCONTIG, bool B_KCONTIG, int NPROD>
-__global__ __launch_bounds__(256, 1) void gemm_bf16x_big_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                                const float* __restrict__ B, int ldb, float* __restrict__ C,
-                                                                int ldc, float beta, int tiles_n, int k_per_split,
-                                                                int use_atomic, unsigned int a_bytes, unsigned int b_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char lds_big[];
-    auto img = [&](int buf, int which) { return lds_big + (buf * 3 + which) * SPLIT_TILE_BYTES; };    // which: A half 0 / 1, B = 2
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * BM2, n0 = (tile % tiles_n) * BN;
-    const int kbeg = blockIdx.y * k_per_split, kend = min(K, kbeg + k_per_split);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    // column tiles of this wave that hold columns of C (wave-uniform)
-    const bool jon[2] = {n0 + wn * 64 < N, n0 + wn * 64 + 32 < N};
-
-    f32x16 acc[4][2], acc_lo[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = acc_lo[i][j][r] = 0.f;
-
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, b_bytes, 0x00020000);
-    float ra[2][2][8], rb[2][8];                          // [register set][A half][8] / [register set][8]
-    int va[2][2], vb[2];
-    split_voffsets<A_KCONTIG>(lda, m0, M, tid, va[0]);
-    split_voffsets<A_KCONTIG>(lda, m0 + 128, M, tid, va[1]);
-    split_voffsets<B_KCONTIG>(ldb, n0, N, tid, vb);
-    const int nslab = (kend - kbeg + BK - 1) / BK;
-    auto load_set = [&](int set, int k0) {
-        split_load<A_KCONTIG>(rsa, va[0], lda, k0, ra[set][0]);
-        split_load<A_KCONTIG>(rsa, va[1], lda, k0, ra[set][1]);
-        split_load<B_KCONTIG>(rsb, vb, ldb, k0, rb[set]);
-    };
-    auto store_set = [&](int set, int buf) {
-        split_store<A_KCONTIG>(img(buf, 0), tid, ra[set][0]);
-        split_store<A_KCONTIG>(img(buf, 1), tid, ra[set][1]);
-        split_store<B_KCONTIG>(img(buf, 2), tid, rb[set]);
-    };
-    if (nslab > 0) load_set(0, kbeg);
-    if (nslab > 1) load_set(1, kbeg + BK);
-    if (nslab > 0) store_set(0, 0);
-    __syncthreads();
-
-    const int lr = lane & 31, lh = lane >> 5;
-    const int a_off = lr * SP + lh * 16, b_off = (wn * 64 + lr) * SP + lh * 16;
-    auto slab = [&](int s, auto PAR) {
-        constexpr int cur = decltype(PAR)::value;
-        load_set(cur, kbeg + (s + 2) * BK);             // (unconditional: see gemm_split_tile_body)
-        const char* as = img(cur, wm) + a_off;
-        const char* bs = img(cur, 2) + b_off;
-        bf16x8 a[4][3], b[2][3];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * SP + q * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8*>(as + i * 32 * SP + q * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                split_mfma2<NPROD>(a[i], b[j], acc[i][j], acc_lo[i][j]);
-        store_set(cur ^ 1, cur ^ 1);
-        // issue order (one wave per SIMD: nobody else fills this wave's stalls): the next-but-one slab's loads, the first
-        // row tile's and both column tiles' fragments, then per MFMA three of the split's vector instructions, an LDS store
-        // every second MFMA and the remaining fragment reads one row tile ahead of their MFMAs
-        constexpr int NMFMA = 48, NVMEM = (A_KCONTIG ? 4 : 16) + (B_KCONTIG ? 2 : 8), NDSW = (A_KCONTIG ? 12 : 6) + (B_KCONTIG ? 6 : 3);
-        __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-#pragma unroll
-        for (int g = 0; g < NMFMA; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            if (g % 12 == 0 && g < 36) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            if (g % 2 == 1 && g / 2 < NDSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        __syncthreads();
-    };
-    for (int s = 0; s < nslab; s += 2) {
-        slab(s, std::integral_constant<int, 0>{});
-        if (s + 1 < nslab) slab(s + 1, std::integral_constant<int, 1>{});
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + lr;
-            if (n >= N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < M) {
-                    float* c = C + (size_t)m * ldc + n;
-                    const float v = acc[i][j][r] + acc_lo[i][j][r];
-                    if (use_atomic)
-                        atomicAdd(c, v);
-                    else
-                        *c = (beta != 0.f) ? v + beta * (*c) : v;
-                }
-            }
-        }
-}
-
 // Kernel family: 0 = f32-input MFMA kernels only, 6 (default) / 9 = the split-operand kernels with that many partial
 // products.  DS2_GEMM_SPLIT sets the process default; ds2_gemm_split_mode() changes it at run time (the tests compare the
 // families in one process).
@@ -831,13 +711,9 @@ inline int gemm_slots() {
     return slots[dev];
 }
 
-// where the 256 x 128 tile is selected (filled in from measurements: tools/gemm_bench.py with DS2_GEMM_BIG = 0 / 2)
-inline bool gemm_big_wins(int M, int N, int K) { (void)M; (void)N; (void)K; return false; }
-
 template <bool AK, bool BKc>
 int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float beta,
            int split_k, hipStream_t st) {
-    const int split_k_in = split_k;
     const int tm = ds2_cdiv(M, BM), tn = ds2_cdiv(N, BN);
     if (split_k == 0) {  // auto: when M*N alone cannot fill the chip (256 CUs x 4 resident 256-thread workgroups), split K.
                          // Measured on the weight-gradient shapes (tools/gemm_split_sweep.py): many small work items
@@ -883,34 +759,14 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
     // (stream-K runs for a partial last round of tiles, as gemm_f32_v2_kernel has them, were built and measured: gi at
         // B = 10, 1292 tiles on 512 slots, 209 -> 204 us, 4096 x 4736 x 800 180 -> 189 us -- these kernels run against the
         // chip's power limit, idle slots give their share back as clock; not kept)
-        // round 6: the 256 x 128 tile, one wave per SIMD (gemm_bf16x_big_kernel).  DS2_GEMM_BIG = 0 / 1 / 2 (tuning builds): never /
-        // by the rule below / always
-        static const int big_env = ds2_tune_env("DS2_GEMM_BIG") ? atoi(ds2_tune_env("DS2_GEMM_BIG")) : 1;
-        static const int big_target = ds2_tune_env("DS2_GEMM_BIG_TARGET") ? atoi(ds2_tune_env("DS2_GEMM_BIG_TARGET")) : 512;
-        if (gemm_split_mode() == 6 && big_env != 0 && (big_env == 2 || gemm_big_wins(M, N, K))) {
-            const int tm2 = ds2_cdiv(M, BM2), tiles2 = tm2 * tn;
-            int sk = split_k_in == 0 ? big_target / tiles2 : split_k_in;
-            const int max_split = K / 320 > 1 ? K / 320 : 1;
-            if (sk > max_split) sk = max_split;
-            if (sk > 32) sk = 32;
-            if (sk < 1) sk = 1;
-            int kper2 = ds2_cdiv(ds2_cdiv(K, sk), BK) * BK;
-            if (kper2 < BK) kper2 = BK;
-            const int nsplit2 = ds2_cdiv(K, kper2);
-            auto kern = &gemm_bf16x_big_kernel<AK, BKc, 6>;
-            static bool attr_set = false;
-            if (!attr_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        BIG_LDS_BYTES) != hipSuccess)
-                    return -2;
-                attr_set = true;
-            }
-            const int atomic2 = nsplit2 > 1 ? 1 : 0;
-            if (atomic2 && beta == 0.f) zero_rows(C, ldc, N, M, st);
-            hipLaunchKernelGGL(kern, dim3(tiles2, nsplit2), dim3(256), BIG_LDS_BYTES, st, M, N, K, A, lda, B, ldb, C, ldc, beta, tn,
-                               kper2, atomic2, (unsigned int)abytes, (unsigned int)bbytes);
-            return 0;
-        }
+        // (round 6, built, measured and removed -- git history: gemm_bf16x_big_kernel -- the 256 x 128 tile with ONE wave per SIMD:
+        // 2 x 2 waves of 128 x 64 outputs = 256 accumulator registers (hi + lo) in the AGPR half, 18 fragment reads for 48 MFMAs
+        // per slab instead of 12 for 24, global loads / split / LDS stores per MFMA x 0.75, 86 KB of LDS, no spills; identical
+        // results.  With the 128 x 128 kernel's issue-order hints: 4096^3 177 -> 167 TFLOP/s (-4 %); input projection at B = 10 /
+        // 64: 194 -> 259 us / 1962 -> 2191 (-25 / -10 %); dX 222 -> 274 / 1985 -> 2518; dW_ih 237 -> 310 / 2302 -> 2877.  A single
+        // wave per SIMD has nobody to fill its own waits (fragment reads behind every slab's barrier, the split's dependent
+        // chains), and round 5's eight-wave form of the same tile -- two waves per SIMD -- gained 3-5 % at most: the loop is
+        // within 1.5x of the 290 TFLOP/s the power-limited clock allows any bf16 loop, and the tile is not what is left)
         dim3 grid(tm * tn, nsplit), block(256);
         const int atomic = nsplit > 1 ? 1 : 0;
         if (atomic && beta == 0.f) zero_rows(C, ldc, N, M, st);
