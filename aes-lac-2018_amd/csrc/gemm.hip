@@ -716,7 +716,7 @@ int launch(int M, int N, int K, const float* A, int lda, const float* B, int ldb
            int split_k, hipStream_t st) {
     const int tm = ds2_cdiv(M, BM), tn = ds2_cdiv(N, BN);
     if (split_k == 0) {  // auto: when M*N alone cannot fill the chip (256 CUs x 4 resident 256-thread workgroups), split K.
-                         // Measured on the weight-gradient shapes (tools/gemm_split_sweep.py): many small work items
+                         // Measured on the weight-gradient shapes (tools/attic/gemm_split_sweep.py): many small work items
                          // beat one round of big ones -- 4800x800x4050 TN: split 3 376 us, 8 318 us, 12 313 us -- so
                          // aim at ~3 items per slot while keeping >= 320 k (20 slabs) per item.
         // Round 2, deep-K shapes with up to two rounds of tiles (dX at B = 32: 13000 x 800 x 4800 = 714 tiles): 1 split

@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2b_kernel(float*
 // backward step.  In the 16-block form block kk (lanes 4kk..4kk+3) takes a DIFFERENT k, A = 4 units (one row
 // group), B = 4 batch columns: one instruction retires 16 k x 4 units x 4 batch columns with no padding beyond
 // rounding B up to a multiple of 4, at 10 cycles per instruction per wave with two waves per SIMD in flight
-// (tools/mfma4x4_probe.hip) against 32 for a 16x16x4.  Every block holds a partial sum over its own k: two DPP
+// (tools/attic/mfma4x4_probe.hip) against 32 for a 16x16x4.  Every block holds a partial sum over its own k: two DPP
 // row_shr adds fold them inside each 16-lane row (lanes 12-15 hold the row's sum) and the gate threads add the
 // remaining 4 rows x 8 waves from LDS.  k order: lane (kk, li) of wave w owns k = 64 G + 4 kk + e, G = w + 8 gi:
 // one dwordx4 feeds the four instructions e = 0..3, for A (weights, resident) and B (the exchange ring) alike.
@@ -2461,7 +2461,7 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// Forward recurrence on v_mfma_f32_4x4x1_16b_f32 with A-operand broadcast (CBSZ / ABID; tools/mfma4x4_bcast_probe.hip:
+// Forward recurrence on v_mfma_f32_4x4x1_16b_f32 with A-operand broadcast (CBSZ / ABID; tools/attic/mfma4x4_bcast_probe.hip:
 // blocks are grouped 2^CBSZ at a time and every block of a group takes its A rows from the group's block ABID).
 //
 // The 16x16x4 kernel above is MFMA-issue bound (tiles r|z and n|pad, 10 of 16 batch columns: 3328 pipe cycles per

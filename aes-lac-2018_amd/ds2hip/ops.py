@@ -585,7 +585,7 @@ def step_stats(costs, sumsq_t, out=None):
     if out is None:
         out = torch.empty((4,), dtype=torch.float64, device=dev)
     # ``out`` may be PAGE-LOCKED HOST memory (its address is valid on the device): the kernel then writes the four values
-    # straight to the host, which polls them (wait_step_stats) -- no copy, no event (tools/readback_probe.py: 14.5 against
+    # straight to the host, which polls them (wait_step_stats) -- no copy, no event (tools/attic/readback_probe.py: 14.5 against
     # 32-34 us from launch to the host having the values)
     lib.call('ds2_step_stats', costs, costs.numel(), sumsq_t, table, len(words), out if out.is_cuda else out.data_ptr())
     return out

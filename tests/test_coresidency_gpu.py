@@ -89,7 +89,7 @@ def test_persistent_steps_beside_a_collective_stand_in(bsz, monkeypatch):
     last bits depend on arrival order, and with ~8 M conv activations per step one of them sits within 1e-7 of the clip
     boundary in about one seed in four (B = 10, seed 10: element 1621927 of conv2's output normalises to -1.4e-8 ..
     -7.9e-8) -- whether its gradient passes is then decided by those last bits, in either kernel family and with or
-    without a neighbour (tools/clip_boundary_probe.py).  One such flip moves conv2's filter gradient by 3 % of its
+    without a neighbour (tools/attic/clip_boundary_probe.py).  One such flip moves conv2's filter gradient by 3 % of its
     largest entry and the NEXT step's loss by 4e-5; the second step is therefore held to 1e-4."""
     from ds2hip import ops
     batches = _batches(bsz, bsz)

@@ -266,7 +266,7 @@ def test_deferred_readback_gives_the_same_steps(frozen_conv):
         runs.append((losses, tr.last_grad_norm, [p.detach().clone() for p in model.parameters()], tr.iteration))
     # Not bit-for-bit: the split-K weight-gradient GEMMs add their partial products with float atomics, in an order that
     # changes from run to run -- two synchronous runs differ in the last bits too.  And the last bits decide on which side of
-    # the conv block's hard clip an activation within 1e-7 of the boundary falls (tools/clip_boundary_probe.py): one such flip
+    # the conv block's hard clip an activation within 1e-7 of the boundary falls (tools/attic/clip_boundary_probe.py): one such flip
     # moves one output channel's conv filter gradient by a few per cent.  So: the first step tightly (same weights), later
     # steps and the parameters with room for a flip -- a step reported twice, skipped or applied out of order would be off by
     # orders of magnitude more.
