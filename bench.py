@@ -593,7 +593,14 @@ def loader_leg(trainer, plan, dev, workers=4):
 def self_launch_command(ngpus, argv, port=None):
     """The command `bench.py --gpus N` (N > 1) runs when no launcher started it: one rank per GPU of this node through
     torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
-    port = port or os.environ.get('MASTER_PORT') or '29531'
+    if not (port or os.environ.get('MASTER_PORT')):
+        # a free port of this host, so that runs launched back to back (N = 2, 4, 8 in a row) never meet a rendezvous port that
+        # the previous run's store has not released yet
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    port = port or os.environ.get('MASTER_PORT')
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ngpus),
             '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
 
