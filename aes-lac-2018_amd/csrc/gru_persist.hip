@@ -1,15 +1,6 @@
 // Persistent BiGRU recurrence kernels for gfx950 (one launch per layer pass).
-#include <stddef.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <mutex>
-#include <type_traits>
-
+#define DS2_PERSIST_MAIN_TU 1
 #include "ds2_common.h"
-#include "split_bf16.h"
-
 // ==========================================================================================================
 // Persistent recurrence: ONE launch per layer pass, recurrent weights resident in VGPRs for all T steps.
 //
@@ -63,1250 +54,9 @@ extern "C" int ds2_debug_read_retries(unsigned int* out, int reset) {
 #define DS2_WTICK(i) do {} while (0)
 #define DS2_RETRY_FLUSH(n) do {} while (0)
 #endif
+#include "gru_persist_common.h"
 
 namespace {
-
-constexpr int NWP = 8;                    // waves per persistent workgroup (2 per SIMD)
-constexpr int PJU = 8;                    // hidden units per workgroup
-constexpr unsigned long long SPIN_TICKS = 500000000ull;  // 5 s of the 100 MHz real-time counter: long enough to
-                                                         // sit out a peer workgroup that is waiting for CUs held by
-                                                         // a concurrent RCCL kernel, short enough to end a lost run
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int NSHARD = 8;  // arrival counters per direction (workgroup x -> shard x % 8), each on its own 128-B line:
-                           // 100 arrivals on ONE word serialise at ~12 ns each (MI355X_MICROARCH.md "fanin")
-struct SyncWs {            // lives in caller-provided device memory: zeroed ONCE by the caller when it is allocated (and
-                           // again after a reported timeout); every launch that completes leaves the counters zero
-    unsigned int arrive[2][3][NSHARD][32];   // [direction][batch part (backward batch-split forms)][shard][line]
-    unsigned int done[32];   // workgroups that have left the kernel; the last one zeroes arrive[] and done for the next launch
-    unsigned int error;      // set to 1 on a spin timeout; STICKY: only the host clears it (ops.raise_async_error)
-};
-
-// Diagnostics that change results (skip the arrival wait / the MFMAs / the store drain, lose an arrival) exist only in
-// builds made with -DDS2_TIMING=1 or -DDS2_FAULT_INJECT=1 (tools/gru_*_timing.py, the lost-arrival test's library):
-// the release library never reads DS2_GRU_DBG.
-#if defined(DS2_TIMING) || defined(DS2_FAULT_INJECT)
-#define DS2_DBG(dbg, bit) ((dbg) & (bit))
-#else
-#define DS2_DBG(dbg, bit) 0
-#endif
-
-// s_waitcnt vmcnt(0) as the BUILTIN (simm16: vmcnt = 0, expcnt and lgkmcnt at their maxima = not waited for), not as inline
-// asm: the compiler's wait-count insertion cannot see into an asm statement, so behind one it still believes the wave's
-// earlier loads are in flight -- and when a later instruction touches one of their destination registers (the loop-carried
-// saved-activation registers of the 4x4x1 kernels) it inserts a vmcnt(0) of its OWN at that point, which then also waits for
-// whatever was issued in between: round 4 found such a wait right behind the hand-off stores (0.4 us per step waiting for
-// the write-through acknowledgements before the next loads could issue), and, in the round-3 kernels, at the top of every step.
-__device__ __forceinline__ void wait_vmcnt0() {
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" ::: "memory");
-}
-// Called by thread 0 of every workgroup that leaves the kernel normally (not on the timeout path: there the host resets
-// the workspace).  The arrival adds of this workgroup have been performed at the memory side once vmcnt is 0; the
-// workgroup whose add to `done` comes last knows every other workgroup has stopped polling and adding, and zeroes the
-// counters with write-through stores: the next launch on the stream starts from zero without a memset in between.
-__device__ __forceinline__ void leave_kernel(SyncWs* sync) {
-    wait_vmcnt0();
-    const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
-    const unsigned int prev = __hip_atomic_fetch_add(&sync->done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == total - 1) {
-        unsigned int* a = &sync->arrive[0][0][0][0];
-        for (int i = 0; i < 2 * 3 * NSHARD; ++i) __hip_atomic_store(a + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&sync->done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// The scalar offset is an OPAQUE zero (an s_mov the optimiser cannot see through).  Without it two hand-off loads of one
-// address are, to the compiler, the same value: the exchange ring is reached through a __restrict__ kernel argument, so not
-// even an asm "memory" barrier between them says that somebody else may have written it -- and the speculative protocol's
-// RE-load of a fragment that still held the canary was folded into the first load's result in one instantiation
-// (gru_bwd_persistent6_kernel<2, ..>, round 6: the retry loop spun on a stale register until the time-out; the instantiations
-// that shipped in rounds 2-5 happened to keep their re-loads -- their retry counters say so -- but nothing guaranteed it).
-__device__ __forceinline__ f32x4 load_sc1_b128(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
-    int zero = 0;
-    asm volatile("" : "+s"(zero));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, zero, 16 /* sc1 */);
-    return __builtin_bit_cast(f32x4, v);
-}
-// hand-off payload load (a timing experiment with plain, L2-allocating loads showed no difference; a run-time
-// switch between the two forms here costs a branch and a vmcnt(0) join in front of the MFMAs)
-#define LOAD_HANDOFF(rs, off) load_sc1_b128(rs, off)
-constexpr int OOB_OFFSET = 0x7FFFFFF0;    // beyond any descriptor's num_records: the range-checked load returns 0
-__device__ __forceinline__ void store_sc1(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Gate nonlinearities on the hardware exp2 / rcp (1 ulp each): the gate math sits on the step's critical path, and the
-// library expf / tanhf / IEEE division cost ~60 more instructions there.  |error| < 3e-7, saturates correctly.
-__device__ __forceinline__ float fast_sigmoid(float x) {
-    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float fast_tanh(float x) {
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
-}
-
-// Speculative hand-off (4x4x1 forms, PROTO = 2; chosen when a workgroup handles one batch quad, i.e. B <= 12).
-// The counted protocol's step is a chain of four dependent memory operations -- payload stores -> their acks (the drain,
-// ~0.45 us) -> arrival add -> (others) poll -> payload loads -- about 2 us of every 3.45 us step at B = 10.  Here a step has
-// TWO: payload stores, payload loads.  There are no per-step counters, no drain before a signal and no poll: a consumer simply
-// loads the slot and checks that what it got is payload.  To make that check possible every ring position is overwritten
-// with CANARY_BITS (a NaN pattern arithmetic never produces; payload values that alias it are re-encoded) TWO steps before
-// its next payload, by the same lane (same address: the stores stay ordered), in a ring of FOUR slots; a wave that finds the
-// pattern in a fragment loads that fragment again (bounded by SPIN_TICKS).  Why a stale payload can never pass for a new
-// one: a workgroup waits for its previous step's stores (a step old, so the wait is free) before it issues a step's
-// payload, so a consumer that has seen producer P's payload of step s knows P's canaries of steps < s have landed -- and it
-// must have seen that payload to finish its own step s + 1, before it reads the slot of step s + 1, whose canary P wrote in
-// step s - 1.  One counted rendezvous per launch covers the start (slots 0 and 1 canaried by everyone before anyone reads).
-// A wave times its first attempt (an adaptive s_sleep count, +1 after a step with a re-load, -1 after four clean ones): a
-// failed attempt costs a round trip and, from 1600 waves, polling traffic.  Measured (H = 800, us per step fwd / bwd):
-// B = 10: 3.48 / 3.44 -> 3.1 / 3.1; B = 8: 2.90 / 2.93 -> 2.45 / 2.55; B = 4: 2.52 / 2.52 -> 1.9 / 2.1.
-// (A "signal first, drain later" variant -- canaries one slot ahead, counters kept, the drain moved behind the arrival add --
-// gained 3 %; it is gone.)
-constexpr unsigned int CANARY_BITS = 0xFFFFFFFFu;
-__device__ __forceinline__ void store_canary(float* p) {
-    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), CANARY_BITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one 16-byte write-through (sc1) store through a WAVE-UNIFORM descriptor + per-lane byte offset (a per-lane descriptor
-// would make the compiler emit a waterfall loop over the lanes)
-__device__ __forceinline__ void store_sc1_b128(__amdgpu_buffer_rsrc_t rs, int byte_off, u32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16 /* sc1 */);
-}
-// a payload value must never look like the canary: a NaN with the all-ones payload (only reachable from NaN inputs carrying
-// that payload) is re-encoded as the canonical quiet NaN -- still a NaN for every consumer
-__device__ __forceinline__ float not_canary(float v) {
-    return __float_as_uint(v) == CANARY_BITS ? __uint_as_float(0x7FC00000u) : v;
-}
-__device__ __forceinline__ bool has_canary(f32x4 v) {
-    const u32x4 u = __builtin_bit_cast(u32x4, v);
-    return (u[0] == CANARY_BITS) | (u[1] == CANARY_BITS) | (u[2] == CANARY_BITS) | (u[3] == CANARY_BITS);
-}
-// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0 .. N - 1 (the MFMA's ABID operand must be an immediate)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-// canary test on the components MASK names (bit e = component e): the k-balanced deal's padding components are never written
-template <int MASK>
-__device__ __forceinline__ bool has_canary_masked(f32x4 v) {
-    const u32x4 u = __builtin_bit_cast(u32x4, v);
-    bool r = false;
-    if (MASK & 1) r |= u[0] == CANARY_BITS;
-    if (MASK & 2) r |= u[1] == CANARY_BITS;
-    if (MASK & 4) r |= u[2] == CANARY_BITS;
-    if (MASK & 8) r |= u[3] == CANARY_BITS;
-    return r;
-}
-
-
-// Speculative protocol: make sure no loaded fragment still holds the canary (returns true if one did).  Runs before the
-// MFMAs; stale fragments are re-loaded per load instruction (a wave-uniform decision) until clean, bounded by SPIN_TICKS like
-// every other spin.  Also adapts the wave's first-attempt delay: +1 after a step that needed a re-load, -1 after 4 clean steps.
-// NVC > 0 (the k-balanced forward deal): only the first NVC components of a lane's NGI loads are ever written (component
-// c of load gi is number 4 gi + c); the others are padding nobody owns and must not be mistaken for a missing payload.
-// G0 .. G1 - 1: the loads this call checks (STAGED consumption, round 4: a k group's fragments are validated right before
-// its own MFMAs, so that the matrix work on the fragments that have landed runs under the wait for the rest -- the chip-wide
-// all-to-all delivers a step's hand-off loads over ~0.8 us, first issued first served: tools/gru_wave_timing.py); `acc`
-// carries "a re-load happened" from stage to stage and the delay adapts once, in the call with `last` set.
-template <int NCI, int NGI, int NVC = 0, int G0 = 0, int G1 = NGI, typename LoadFrag>
-__device__ __forceinline__ bool validate_fragments(f32x4 (&bf)[NCI][NGI], LoadFrag& load_frag, bool first_chunk, int spec,
-                                                   int& spec_delay, int& spec_clean, SyncWs* sync, int& abort_flag,
-                                                   int& nretry, bool* acc = nullptr, bool last = true) {
-    bool retried = false;
-    unsigned long long t_retry = 0;
-    auto has_canary = [](f32x4 v, auto gi_tag) {
-        constexpr int gi = decltype(gi_tag)::value;
-        constexpr int left = NVC > 0 ? NVC - 4 * gi : 4;
-        return has_canary_masked<(left >= 4 ? 15 : (1 << (left > 0 ? left : 0)) - 1)>(v);
-    };
-    if constexpr (NCI * (G1 - G0) <= 2) {   // the common case -- every fragment already holds payload -- costs ONE ballot (with the
-                                      // backward kernel's five fragments the joint test measured 0.05 us per step SLOWER)
-        bool stale = false;
-        static_for<G0, G1>([&](auto gi_tag) {
-#pragma unroll
-            for (int ci = 0; ci < NCI; ++ci) stale |= has_canary(bf[ci][decltype(gi_tag)::value], gi_tag);
-        });
-        if (!__any(stale)) goto validated;
-    }
-    for (;;) {
-        asm volatile("" ::: "memory");                            // (keeps re-loads from being hoisted or merged)
-        bool any = false;
-        static_for<G0, G1>([&](auto gi_tag) {
-            constexpr int gi = decltype(gi_tag)::value;
-#pragma unroll
-            for (int ci = 0; ci < NCI; ++ci)
-                if (__any(has_canary(bf[ci][gi], gi_tag))) {
-                    any = true;
-                    load_frag(ci, gi);
-                }
-        });
-        if (!any) break;
-        ++nretry;
-        retried = true;
-        for (int i = 0; i < ((spec >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(1);
-        if (t_retry == 0) t_retry = __builtin_amdgcn_s_memrealtime();
-        if (__builtin_amdgcn_s_memrealtime() - t_retry > SPIN_TICKS) {   // a payload never came: flag it, leave the launch
-            if ((threadIdx.x & 63) == 0) {
-                __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                abort_flag = 1;
-            }
-            break;
-        }
-    }
-    // Round 6: behind the re-load loop NOTHING is in flight.  The loop's exits are decided by scalar masks the compiler's
-    // wait-count pass cannot follow, so it merged "a re-issued load is this wave's YOUNGEST operation" into the join with the
-    // one-ballot fast path above and put a vmcnt(0) in front of the first MFMA of EVERY step -- the later fragments' staged
-    // consumption never happened on the fast path either (seen in the ISA of gru_fwd_persistent5_kernel: vmcnt(1), ballot,
-    // then vmcnt(0) before the first of the 64 MFMAs).  With this wait on the slow path only, the join needs none.
-    if constexpr (NCI * (G1 - G0) <= 2) wait_vmcnt0();
-validated:
-    if (acc) {
-        *acc |= retried;
-        retried = *acc;
-    }
-    if (!last) return retried;
-    if (((spec >> 16) & 1) && first_chunk) {
-        if (retried) {
-            spec_delay = min(spec_delay + ((spec >> 18) & 3), 63);
-            spec_clean = 0;
-        } else if (++spec_clean == (1 << ((spec >> 20) & 7))) {
-            spec_clean = 0;
-            spec_delay = max(spec_delay - 1, 0);
-        }
-    }
-    // wave-uniform by construction (every decision above is a ballot): tell the compiler, so that the first-attempt sleep
-    // and this bookkeeping are scalar code instead of exec-masked vector loops
-    spec_delay = __builtin_amdgcn_readfirstlane(spec_delay);
-    spec_clean = __builtin_amdgcn_readfirstlane(spec_clean);
-    return retried;
-}
-
-// wave 0 only (all 64 lanes call it): lane l < NSHARD polls shard l until it holds step * (slices in that shard)
-// arrivals; returns false on timeout.
-__device__ __forceinline__ bool wait_arrivals(unsigned int* shards, int step, int nslice, int lane,
-                                              unsigned int* err) {
-    const unsigned int target = (unsigned int)step * (unsigned int)((nslice - lane + NSHARD - 1) / NSHARD);
-    const bool poller = lane < NSHARD && lane < nslice;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-        bool ok = true;
-        if (poller)
-            ok = __hip_atomic_load(shards + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
-        if (__all(ok)) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > SPIN_TICKS) {
-            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-    }
-}
-
-template <int NBT, int KBW>
-__global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_kernel(float* __restrict__ G, float* __restrict__ ghn,
-                                                                      float* __restrict__ hout,
-                                                                      const float* __restrict__ w_hh,
-                                                                      SyncWs* __restrict__ sync, float* __restrict__ ring,
-                                                                      int T, int B, int H, int dbg) {
-    __shared__ float red[NWP][2][NBT][16][17];
-    __shared__ int abort_flag;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    // readfirstlane makes everything derived from the wave id provably wave-uniform: uniform branches and SGPR
-    // buffer descriptors instead of per-load waterfall loops (cdna_hip_programming.md T20)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, nslice = gridDim.x;
-    const int j0 = blockIdx.x * PJU;
-    const int m = lane & 15, q = lane >> 4;
-    const int nkb = H >> 4;
-    if (tid == 0) abort_flag = 0;
-
-    // ---- resident weights: tile 0 rows = [r units | z units], tile 1 rows = [n units | unused]
-    f32x4 wreg[2][KBW];
-    {
-        const int mj = m & 7, hi = m >> 3;
-        const bool unit_ok = (j0 + mj) < H;
-        const float* row0 = w_hh + ((size_t)dir * 3 * H + (size_t)(hi ? H : 0) + j0 + mj) * H;      // r or z
-        const float* row1 = w_hh + ((size_t)dir * 3 * H + (size_t)2 * H + j0 + mj) * H;              // n
-#pragma unroll
-        for (int i = 0; i < KBW; ++i) {
-            const int kb = wave + NWP * i;
-            const bool ok = kb < nkb && unit_ok;
-            const int k = kb * 16 + q * 4;
-            wreg[0][i] = ok ? *reinterpret_cast<const f32x4*>(row0 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-            wreg[1][i] = (ok && hi == 0) ? *reinterpret_cast<const f32x4*>(row1 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    // ---- gate-thread role
-    const int jj = tid & 7, nn = (tid >> 3) & 15, gbt = tid >> 7;
-    const int gb = gbt * 16 + nn, gj = j0 + jj;
-    const bool gate_ok = (gbt < NBT) && (gb < B) && (gj < H);
-    float hp = 0.f;                                     // this thread's h_{t-1}, carried in a register
-    unsigned int* shards = &sync->arrive[dir][0][0][0];
-    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? s : T - 1 - s;
-        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f, sv_h = 0.f;
-        size_t gbase = 0;
-        if (gate_ok) {                                  // independent of h: issue before the wait
-            gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
-            gi_r = G[gbase];
-            gi_z = G[gbase + H];
-            gi_n = G[gbase + 2 * H];
-        }
-        if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
-                abort_flag = 1;
-            __syncthreads();
-            if (abort_flag) return;
-            // h_{t-1} comes from the exchange ring, laid out [batch tile][k block][k quad 4][16 batch rows][4 k]: the
-            // MFMA B fragment of lane l is bytes 16 l .. 16 l + 15 of ONE contiguous kilobyte, so a wave-load is eight
-            // whole 128-B lines read in lane order (the (b, k) layout of hout gives 10-16 scattered 64-B pieces per
-            // load and ran the CU's inbound path at ~27 GB/s; a [16 batch][16 k] block is contiguous per wave but
-            // each 16-lane quarter still gathers four 64-B pieces and measured ~1 us/step slower)
-            const int slot_floats = NBT * nkb * 256;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
-            // batch tiles are software-pipelined: the h fragments of tile bt+1 are in flight while the MFMAs of
-            // tile bt issue (fully unrolled so the two fragment buffers stay in registers)
-            f32x4 bf[2][KBW];
-            auto fetch = [&](int bt, f32x4 (&dst)[KBW]) {
-#pragma unroll
-                for (int i = 0; i < KBW; ++i) {
-                    const int kb = wave + NWP * i;                 // wave-uniform
-                    // rows of padding batch entries hold whatever an earlier launch left: their products land in
-                    // output columns >= B, which no gate thread reads
-                    // k blocks past the end: an offset beyond the descriptor's range reads as zero, with no branch
-                    dst[i] = LOAD_HANDOFF(rsrc, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
-                }
-            };
-            if (!DS2_DBG(dbg, 2)) {
-                fetch(0, bf[0]);
-#pragma unroll
-                for (int bt = 0; bt < NBT; ++bt) {
-                    if (bt + 1 < NBT) fetch(bt + 1, bf[(bt + 1) & 1]);
-                    // all loads out before the MFMAs (the scheduler would otherwise sink them in between, 2 in flight)
-                    __builtin_amdgcn_sched_barrier(0);
-                    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-                    for (int i = 0; i < KBW; ++i) {
-                        // the step is MFMA-issue bound: a wave whose last k block lies past H (H = 800: 50 blocks
-                        // over 8 waves, six of them own 6 not 7) skips its 8 all-zero MFMAs (wave-uniform branch)
-                        if (i == KBW - 1 && wave + NWP * i >= nkb) break;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[0][i][e], bf[bt & 1][i][e], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[1][i][e], bf[bt & 1][i][e], acc1, 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        red[wave][0][bt][4 * q + r][m] = acc0[r];
-                        red[wave][1][bt][4 * q + r][m] = acc1[r];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (gate_ok) {
-            float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
-            if (s > 0) {
-#pragma unroll
-                for (int w = 0; w < NWP; ++w) {
-                    gh_r += red[w][0][gbt][jj][nn];
-                    gh_z += red[w][0][gbt][8 + jj][nn];
-                    gh_n += red[w][1][gbt][jj][nn];
-                }
-            }
-            const float r = fast_sigmoid(gi_r + gh_r);
-            const float z = fast_sigmoid(gi_z + gh_z);
-            const float n = fast_tanh(gi_n + r * gh_n);
-            const float h = (1.f - z) * n + z * hp;
-            hp = h;
-            // handed to every other workgroup through the ring; hout keeps the plain copy for later launches
-            store_sc1(&ring[(((size_t)dir * 2 + (s & 1)) * NBT * nkb + (size_t)gbt * nkb + (gj >> 4)) * 256 +
-                            ((gj & 15) >> 2) * 64 + nn * 4 + (gj & 3)], h);
-            sv_h = h;
-            sv_r = r;
-            sv_z = z;
-            sv_n = n;
-            sv_g = gh_n;
-        }
-        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();   // every storing wave drains its hand-off store
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gate_ok) {   // saved activations are only read by later launches: keep them off the hand-off's critical path
-            hout[(((size_t)dir * T + t) * B + gb) * H + gj] = sv_h;
-            G[gbase] = sv_r;
-            G[gbase + H] = sv_z;
-            G[gbase + 2 * H] = sv_n;
-            ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g;
-        }
-    }
-    if (tid == 0) leave_kernel(sync);
-}
-
-// Forward recurrence, 16x16x4 form with TWO batch parts (blockIdx.z): a workgroup owns 16 units and half the batch, so
-// its gate rows fill three whole tiles (r16, z16, n16; the 8-unit form above pads its second tile by half) and it loads
-// half the hidden state per step.  For B >= 24: per wave and batch tile 3 x KBW x 4 MFMAs instead of 2 x 2 x KBW x 4 for
-// the two tiles a whole batch of 32 needs.  NBT = batch tiles of 16 per part (1 or 2).
-template <int NBT, int KBW>
-__global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2_kernel(float* __restrict__ G, float* __restrict__ ghn,
-                                                                         float* __restrict__ hout,
-                                                                         const float* __restrict__ w_hh,
-                                                                         SyncWs* __restrict__ sync,
-                                                                         float* __restrict__ ring, int T, int B, int H,
-                                                                         int dbg) {
-    __shared__ float red[NWP][3][NBT][16][17];
-    __shared__ int abort_flag;
-    constexpr int UNITS = 16;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
-    const int j0 = blockIdx.x * UNITS;
-    const int m = lane & 15, q = lane >> 4;
-    const int nkb = H >> 4;
-    const int bper = (B + 1) / 2, b0 = part * bper, nb = min(bper, B - b0);
-    if (nb <= 0) {
-        if (tid == 0) leave_kernel(sync);
-        return;
-    }
-    const int slot_floats = NBT * nkb * 256;
-    float* my_ring = ring + (size_t)(dir * 2 + part) * 2 * slot_floats;
-    if (tid == 0) abort_flag = 0;
-
-    f32x4 wreg[3][KBW];                                 // tile g = gate g of units j0 .. j0 + 15 (row m)
-    {
-        const bool unit_ok = (j0 + m) < H;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const float* row = w_hh + ((size_t)dir * 3 * H + (size_t)g * H + (unit_ok ? j0 + m : 0)) * H;
-#pragma unroll
-            for (int i = 0; i < KBW; ++i) {
-                const int kb = wave + NWP * i;
-                wreg[g][i] = (kb < nkb && unit_ok) ? *reinterpret_cast<const f32x4*>(row + kb * 16 + q * 4)
-                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    }
-    // gate role: unit jj, local batch row 16 gbt + nn  (512 threads = 16 units x 32 rows)
-    const int jj = tid & 15, nn = (tid >> 4) & 15, gbt = tid >> 8;
-    const int lb = gbt * 16 + nn, gb = b0 + lb, gj = j0 + jj;
-    const bool gate_ok = (gbt < NBT) && (lb < nb) && (gj < H);
-    float hp = 0.f;
-    unsigned int* shards = &sync->arrive[dir][part][0][0];
-    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? s : T - 1 - s;
-        float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f, sv_h = 0.f;
-        size_t gbase = 0;
-        if (gate_ok) {                                  // independent of h: issue before the wait
-            gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
-            gi_r = G[gbase];
-            gi_z = G[gbase + H];
-            gi_n = G[gbase + 2 * H];
-        }
-        if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
-                abort_flag = 1;
-            __syncthreads();
-            if (abort_flag) return;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
-            f32x4 bf[2][KBW];
-            auto fetch = [&](int bt, f32x4 (&dst)[KBW]) {
-#pragma unroll
-                for (int i = 0; i < KBW; ++i) {
-                    const int kb = wave + NWP * i;                 // wave-uniform
-                    dst[i] = LOAD_HANDOFF(rsrc, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
-                }
-            };
-            if (!DS2_DBG(dbg, 2)) {
-                fetch(0, bf[0]);
-#pragma unroll
-                for (int bt = 0; bt < NBT; ++bt) {
-                    if (bt + 1 < NBT) fetch(bt + 1, bf[(bt + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);             // all loads out before the MFMAs
-                    f32x4 acc[3];
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < KBW; ++i) {
-                        if (i == KBW - 1 && wave + NWP * i >= nkb) break;   // all-zero padded k block
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int g = 0; g < 3; ++g)
-                                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[g][i][e], bf[bt & 1][i][e], acc[g], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) red[wave][g][bt][4 * q + r][m] = acc[g][r];
-                }
-            }
-        }
-        __syncthreads();
-        if (gate_ok) {
-            float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
-            if (s > 0) {
-#pragma unroll
-                for (int w = 0; w < NWP; ++w) {
-                    gh_r += red[w][0][gbt][jj][nn];
-                    gh_z += red[w][1][gbt][jj][nn];
-                    gh_n += red[w][2][gbt][jj][nn];
-                }
-            }
-            const float r = fast_sigmoid(gi_r + gh_r);
-            const float z = fast_sigmoid(gi_z + gh_z);
-            const float n = fast_tanh(gi_n + r * gh_n);
-            const float h = (1.f - z) * n + z * hp;
-            hp = h;
-            sv_h = h;
-            sv_r = r;
-            sv_z = z;
-            sv_n = n;
-            sv_g = gh_n;
-        }
-        {
-            // exchange ring of this (direction, part): [batch tile][k block][k quad 4][16 batch rows][4 k].  Four neighbouring
-            // gate threads (units 4u .. 4u+3 of one batch row: adjacent lanes, 16 contiguous bytes of the ring) hand their
-            // values to the first of them, which issues ONE 16-byte write-through store: a quarter of the fabric writes
-            // (a 4-byte sc1 store costs about six times a 16-byte one per byte).  H % 16 == 0: a quad never straddles H.
-            f32x4 hq;
-            hq[0] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_h), 0x00, 0xF, 0xF, true));
-            hq[1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_h), 0x55, 0xF, 0xF, true));
-            hq[2] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_h), 0xAA, 0xF, 0xF, true));
-            hq[3] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_h), 0xFF, 0xF, 0xF, true));
-            if (gate_ok && (jj & 3) == 0) {
-                const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, 2 * slot_floats * 4, 0x00020000);
-                store_sc1_b128(rs_w, ((s & 1) * slot_floats + (gbt * nkb + (gj >> 4)) * 256 + ((gj & 15) >> 2) * 64 + nn * 4) * 4,
-                               __builtin_bit_cast(u32x4, hq));
-            }
-        }
-        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gate_ok) {
-            hout[(((size_t)dir * T + t) * B + gb) * H + gj] = sv_h;
-            G[gbase] = sv_r;
-            G[gbase + H] = sv_z;
-            G[gbase + 2 * H] = sv_n;
-            ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g;
-        }
-    }
-    if (tid == 0) leave_kernel(sync);
-}
-
-// ----------------------------------------------------------------------------------------------------------
-// The two-part 16x16 forms on the bf16 matrix pipe (B >= 17, H % 32 == 0).  From B = 17 half of a recurrence step is
-// matrix-pipe time (16 units x 16 batch rows x 3 H k per workgroup on v_mfma_f32_16x16x4_f32: 84 / 76 instructions of 32
-// cycles per wave and batch tile).  Here every fp32 operand is split without error into three bf16 terms (split_bf16.h) and
-// the products run on v_mfma_f32_16x16x32_bf16 -- six exact partial products per 32 k, 16 cycles each: 0.43 x the pipe time
-// for the same fp32 result (the accumulator is fp32 as before).  The weights are split once per launch into registers
-// (three planes of 8 bf16 per lane and 32-k block: 1.5 x the registers of the fp32 copy); the NEW state is split by the
-// gate thread that produces it and written to the exchange ring as three bf16 planes, eight units per 16-byte write-through
-// store (two neighbours' values are packed by one split, the four dwords of an octet gathered with DPP) -- 1.5 x the
-// hand-off bytes, no conversion on the consumers' side.
-// Ring layout of a (direction, part): [slot 2][batch tile][k block of 32][plane 3][k octet 4][16 batch rows][8 k] bf16: a
-// wave-load of one plane of one block is 1 KB contiguous, lane l = (batch row l & 15, octet l >> 4).
-// ----------------------------------------------------------------------------------------------------------
-typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
-
-// the octet gather of one plane: lanes 8 o + {0, 2, 4, 6} hold the packed pairs; lane 8 o receives all four
-__device__ __forceinline__ u32x4 gather_octet(unsigned int pair) {
-    const int p = (int)pair;
-    const int x1 = __builtin_amdgcn_update_dpp(0, p, 0xAA, 0xF, 0xF, true);      // quad lane 2's pair
-    const int x2 = __builtin_amdgcn_update_dpp(0, p, 0x104, 0xF, 0xF, true);     // row_shl:4 -> lane + 4's pair
-    const int x3 = __builtin_amdgcn_update_dpp(0, x1, 0x104, 0xF, 0xF, true);    // lane + 6's pair
-    u32x4 v;
-    v[0] = pair;
-    v[1] = (unsigned int)x1;
-    v[2] = (unsigned int)x2;
-    v[3] = (unsigned int)x3;
-    return v;
-}
-// split this thread's value together with its odd neighbour's (lanes 2 i, 2 i + 1 hold units 2 i, 2 i + 1 of one batch row)
-// and gather the octet: planes[q] is valid in lanes with (unit & 7) == 0
-__device__ __forceinline__ void split_gather_octet(float v, u32x4 (&planes)[3]) {
-    const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
-    unsigned int p1, p2, p3;
-    split3(v, nb, p1, p2, p3);
-    planes[0] = gather_octet(p1);
-    planes[1] = gather_octet(p2);
-    planes[2] = gather_octet(p3);
-}
-
-template <int NBT, int KBW>
-__global__ __launch_bounds__(NWP * 64) void gru_fwd_persistent_p2b_kernel(float* __restrict__ G, float* __restrict__ ghn,
-                                                                          float* __restrict__ hout,
-                                                                          const float* __restrict__ w_hh,
-                                                                          SyncWs* __restrict__ sync,
-                                                                          float* __restrict__ ring, int T, int B, int H,
-                                                                          int dbg) {
-    __shared__ float red[NWP][3][NBT][16][17];
-    __shared__ int abort_flag;
-    constexpr int UNITS = 16;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
-    const int j0 = blockIdx.x * UNITS;
-    const int m = lane & 15, q = lane >> 4;
-    const int nkb = H >> 5;                             // k blocks of 32
-    const int bper = (B + 1) / 2, b0 = part * bper, nb = min(bper, B - b0);
-    if (nb <= 0) {
-        if (tid == 0) leave_kernel(sync);
-        return;
-    }
-    const int slot_bytes = NBT * nkb * 3 * 1024;
-    char* my_ring = reinterpret_cast<char*>(ring) + (size_t)(dir * 2 + part) * 2 * slot_bytes;
-    if (tid == 0) abort_flag = 0;
-
-    gbf16x8 wq[3][KBW][3];                              // [gate][k block][plane]: row m = unit j0 + m, k = 32 kb + 8 q ..
-    {
-        const bool unit_ok = (j0 + m) < H;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const float* row = w_hh + ((size_t)dir * 3 * H + (size_t)g * H + (unit_ok ? j0 + m : 0)) * H;
-#pragma unroll
-            for (int i = 0; i < KBW; ++i) {
-                const int kb = wave + NWP * i;
-                f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-                if (kb < nkb && unit_ok) {
-                    lo = *reinterpret_cast<const f32x4*>(row + kb * 32 + q * 8);
-                    hi = *reinterpret_cast<const f32x4*>(row + kb * 32 + q * 8 + 4);
-                }
-                unsigned int pl[3][4];
-                split3(lo[0], lo[1], pl[0][0], pl[1][0], pl[2][0]);
-                split3(lo[2], lo[3], pl[0][1], pl[1][1], pl[2][1]);
-                split3(hi[0], hi[1], pl[0][2], pl[1][2], pl[2][2]);
-                split3(hi[2], hi[3], pl[0][3], pl[1][3], pl[2][3]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const u32x4 v = {pl[c][0], pl[c][1], pl[c][2], pl[c][3]};
-                    wq[g][i][c] = __builtin_bit_cast(gbf16x8, v);
-                }
-            }
-        }
-    }
-    // gate role: unit jj, local batch row 16 gbt + nn  (512 threads = 16 units x 32 rows)
-    const int jj = tid & 15, nn = (tid >> 4) & 15, gbt = tid >> 8;
-    const int lb = gbt * 16 + nn, gb = b0 + lb, gj = j0 + jj;
-    const bool gate_ok = (gbt < NBT) && (lb < nb) && (gj < H);
-    float hp = 0.f;
-    unsigned int* shards = &sync->arrive[dir][part][0][0];
-    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
-    __syncthreads();
-
-    // Round 4 (as in the 4x4x1 kernels): the gate pre-activations of step s + 1 are loaded at the END of step s, behind the
-    // saved-activation stores, instead of at the top of step s + 1 in front of its hand-off loads (a wave's vector-memory
-    // operations complete in issue order)
-    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
-    auto load_gi = [&](int t) {
-        if (gate_ok) {
-            const size_t gb3 = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
-            gi_r = G[gb3];
-            gi_z = G[gb3 + H];
-            gi_n = G[gb3 + 2 * H];
-        }
-    };
-    load_gi(dir == 0 ? 0 : T - 1);
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? s : T - 1 - s;
-        float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f, sv_h = 0.f;
-        const size_t gbase = (((size_t)t * B + gb) * 2 + dir) * 3 * H + gj;
-        if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
-                abort_flag = 1;
-            __syncthreads();
-            if (abort_flag) return;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                my_ring + (size_t)((s - 1) & 1) * slot_bytes, 0, slot_bytes, 0x00020000);
-            if (!DS2_DBG(dbg, 2)) {
-#pragma unroll
-                for (int bt = 0; bt < NBT; ++bt) {
-                    gbf16x8 bf[KBW][3];
-#pragma unroll
-                    for (int i = 0; i < KBW; ++i) {
-                        const int kb = wave + NWP * i;                 // wave-uniform
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            bf[i][c] = __builtin_bit_cast(
-                                gbf16x8, LOAD_HANDOFF(rsrc, (kb < nkb) ? ((bt * nkb + kb) * 3 + c) * 1024 + lane * 16 : OOB_OFFSET));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);                 // all loads out before the MFMAs
-                    f32x4 acc[3];
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < KBW; ++i) {
-                        if (i == KBW - 1 && wave + NWP * i >= nkb) break;   // all-zero padded k block
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            f32x4 a = acc[g];
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[g][i][1], bf[i][1], a, 0, 0, 0);
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[g][i][0], bf[i][2], a, 0, 0, 0);
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[g][i][2], bf[i][0], a, 0, 0, 0);
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[g][i][0], bf[i][1], a, 0, 0, 0);
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[g][i][1], bf[i][0], a, 0, 0, 0);
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[g][i][0], bf[i][0], a, 0, 0, 0);
-                            acc[g] = a;
-                        }
-                    }
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) red[wave][g][bt][4 * q + r][m] = acc[g][r];
-                }
-            }
-        }
-        __syncthreads();
-        if (gate_ok) {
-            float gh_r = 0.f, gh_z = 0.f, gh_n = 0.f;
-            if (s > 0) {
-#pragma unroll
-                for (int w = 0; w < NWP; ++w) {
-                    gh_r += red[w][0][gbt][jj][nn];
-                    gh_z += red[w][1][gbt][jj][nn];
-                    gh_n += red[w][2][gbt][jj][nn];
-                }
-            }
-            const float r = fast_sigmoid(gi_r + gh_r);
-            const float z = fast_sigmoid(gi_z + gh_z);
-            const float n = fast_tanh(gi_n + r * gh_n);
-            const float h = (1.f - z) * n + z * hp;
-            hp = h;
-            sv_h = h;
-            sv_r = r;
-            sv_z = z;
-            sv_n = n;
-            sv_g = gh_n;
-        }
-        {
-            u32x4 planes[3];
-            split_gather_octet(sv_h, planes);                          // (every lane: DPP needs the whole row active)
-            if (gate_ok && (jj & 7) == 0) {
-                const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, 2 * slot_bytes, 0x00020000);
-                const int base = (s & 1) * slot_bytes + (gbt * nkb + (gj >> 5)) * 3 * 1024 + ((gj & 31) >> 3) * 256 + nn * 16;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) store_sc1_b128(rs_w, base + c * 1024, planes[c]);
-            }
-        }
-        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gate_ok) {
-            hout[(((size_t)dir * T + t) * B + gb) * H + gj] = sv_h;
-            G[gbase] = sv_r;
-            G[gbase + H] = sv_z;
-            G[gbase + 2 * H] = sv_n;
-            ghn[(((size_t)t * B + gb) * 2 + dir) * H + gj] = sv_g;
-        }
-        if (s + 1 < T) load_gi(dir == 0 ? s + 1 : T - 2 - s);
-    }
-    if (tid == 0) leave_kernel(sync);
-}
-
-template <int NBT, int KBW>
-__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_kernel(float* __restrict__ G, float* __restrict__ ghn,
-                                                                      const float* __restrict__ hout,
-                                                                      const float* __restrict__ d_out,
-                                                                      const float* __restrict__ w_hh_t,
-                                                                      SyncWs* __restrict__ sync, float* __restrict__ ring,
-                                                                      int T, int B, int H, int dbg) {
-    __shared__ float red[NWP][NBT][16][17];
-    __shared__ int abort_flag;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    // readfirstlane makes everything derived from the wave id provably wave-uniform: uniform branches and SGPR
-    // buffer descriptors instead of per-load waterfall loops (cdna_hip_programming.md T20)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, nslice = gridDim.x;
-    const int j0 = blockIdx.x * PJU;
-    const int m = lane & 15, q = lane >> 4;
-    const int K = 3 * H, nkb = K >> 4;
-    if (tid == 0) abort_flag = 0;
-
-    f32x4 wreg[KBW];                                   // rows m < 8: column (j0+m) of W_hh = row of w_hh_t
-    {
-        const bool row_ok = (m < PJU) && (j0 + m < H);
-        const float* row = w_hh_t + ((size_t)dir * H + j0 + (m & 7)) * K;
-#pragma unroll
-        for (int i = 0; i < KBW; ++i) {
-            const int kb = wave + NWP * i;
-            wreg[i] = (row_ok && kb < nkb) ? *reinterpret_cast<const f32x4*>(row + kb * 16 + q * 4)
-                                           : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    const int jj = tid & 7, nn = (tid >> 3) & 15, gbt = tid >> 7;
-    const int gb = gbt * 16 + nn, gj = j0 + jj;
-    const bool gate_ok = (gbt < NBT) && (gb < B) && (gj < H);
-    float dhz = 0.f;                                    // dh * z carried to the next (earlier) step
-    unsigned int* shards = &sync->arrive[dir][0][0][0];
-    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? T - 1 - s : s;
-        const int tnext = dir == 0 ? t + 1 : t - 1;
-        const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
-        // saved activations of step t (written by the forward pass, an earlier launch): plain loads
-        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
-        size_t row = 0, gbase = 0;
-        if (gate_ok) {
-            row = ((size_t)t * B + gb) * 2 + dir;
-            gbase = row * 3 * H + gj;
-            dh = d_out[((size_t)t * B + gb) * H + gj];
-            r = G[gbase];
-            z = G[gbase + H];
-            n = G[gbase + 2 * H];
-            gn = ghn[row * H + gj];
-            if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
-        }
-        if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
-                abort_flag = 1;
-            __syncthreads();
-            if (abort_flag) return;
-            // dGH of step tnext = [dr_pre | dz_pre | d(gh_n)] comes from the exchange ring, laid out
-            // [batch tile][k block][16 batch rows][16 k]: one wave-load = one contiguous kilobyte
-            const int slot_floats = NBT * nkb * 256;
-            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-                ring + ((size_t)dir * 2 + ((s - 1) & 1)) * slot_floats, 0, slot_floats * 4, 0x00020000);
-            // stages = (batch tile, k chunk); the fragments of stage st+1 are fetched while stage st's MFMAs issue
-            constexpr int CH = (NBT > 1 && KBW > 10) ? 7 : KBW;
-            constexpr int NCH = (KBW + CH - 1) / CH;
-            constexpr int NST = NBT * NCH;
-            f32x4 bf[2][CH];
-            auto fetch = [&](int st, f32x4 (&dst)[CH]) {
-                const int bt = st / NCH, i0 = (st % NCH) * CH;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int i = i0 + c;
-                    const int kb = wave + NWP * i;                 // wave-uniform
-                    if (i < KBW)                                   // compile-time
-                        dst[c] = LOAD_HANDOFF(rs_x, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
-                    else
-                        dst[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            };
-            if (!DS2_DBG(dbg, 2)) {
-                fetch(0, bf[0]);
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int st = 0; st < NST; ++st) {
-                    if (st + 1 < NST) fetch(st + 1, bf[(st + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);   // loads out before the MFMAs
-                    const int bt = st / NCH, i0 = (st % NCH) * CH;
-#pragma unroll
-                    for (int c = 0; c < CH; ++c)
-                        if (i0 + c < KBW) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i0 + c][e], bf[st & 1][c][e], acc, 0, 0, 0);
-                        }
-                    if ((st % NCH) == NCH - 1) {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) red[wave][bt][4 * q + rr][m] = acc[rr];
-                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (gate_ok) {
-            if (s > 0) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < NWP; ++w) a += red[w][gbt][jj][nn];
-                dh += a + dhz;
-            }
-            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
-            const float dz_pre = dh * (hpv - n) * z * (1.f - z);
-            const float dr_pre = dn_pre * gn * r * (1.f - r);
-            dhz = dh * z;
-            {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j
-                float* slot = ring + (((size_t)dir * 2 + (s & 1)) * NBT + gbt) * (size_t)nkb * 256 + nn * 4;
-                const int k0 = gj, k1 = H + gj, k2 = 2 * H + gj;
-                store_sc1(&slot[(size_t)(k0 >> 4) * 256 + ((k0 & 15) >> 2) * 64 + (k0 & 3)], dr_pre);
-                store_sc1(&slot[(size_t)(k1 >> 4) * 256 + ((k1 & 15) >> 2) * 64 + (k1 & 3)], dz_pre);
-                store_sc1(&slot[(size_t)(k2 >> 4) * 256 + ((k2 & 15) >> 2) * 64 + (k2 & 3)], dn_pre * r);
-            }
-            sv_r = dr_pre;
-            sv_z = dz_pre;
-            sv_n = dn_pre;
-            sv_g = dn_pre * r;
-        }
-        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
-            G[gbase] = sv_r;
-            G[gbase + H] = sv_z;
-            G[gbase + 2 * H] = sv_n;
-            ghn[row * H + gj] = sv_g;
-        }
-    }
-    if (tid == 0) leave_kernel(sync);
-}
-
-// Backward recurrence, 16x16x4 form with TWO batch parts (blockIdx.z), the twin of gru_fwd_persistent_p2_kernel: a
-// workgroup owns 16 units -- 16 rows of w_hh_t, a whole MFMA tile (the 8-unit form above pads half of every tile) -- and
-// half the batch, so per step it pulls HALF of d(gh) (150 KB at B = 32 instead of 300) and issues NBT x 150 / 8 x 4 MFMAs
-// per wave.  For B >= 17: the 4x4x1 forms' cost grows with every batch quad (B = 32: 7.0 us per step, B = 64: 12.3), this
-// form's with every tile of 16 rows per part.  The hand-off loads of k chunk c + 1 are in flight under the MFMAs of chunk c.
-template <int NBT, int KBW>
-__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2_kernel(float* __restrict__ G, float* __restrict__ ghn,
-                                                                         const float* __restrict__ hout,
-                                                                         const float* __restrict__ d_out,
-                                                                         const float* __restrict__ w_hh_t,
-                                                                         SyncWs* __restrict__ sync, float* __restrict__ ring,
-                                                                         int T, int B, int H, int dbg) {
-    __shared__ float red[NWP][NBT][16][17];
-    __shared__ int abort_flag;
-    constexpr int UNITS = 16;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
-    const int j0 = blockIdx.x * UNITS;
-    const int m = lane & 15, q = lane >> 4;
-    const int K = 3 * H, nkb = K >> 4;
-    const int bper = (B + 1) / 2, b0 = part * bper, nb = min(bper, B - b0);
-    if (nb <= 0) {
-        if (tid == 0) leave_kernel(sync);
-        return;
-    }
-    const int slot_floats = NBT * nkb * 256;
-    float* my_ring = ring + (size_t)(dir * 2 + part) * 2 * slot_floats;
-    if (tid == 0) abort_flag = 0;
-
-    f32x4 wreg[KBW];                                   // row m: column (j0 + m) of W_hh = row of w_hh_t
-    {
-        const bool unit_ok = (j0 + m) < H;
-        const float* row = w_hh_t + ((size_t)dir * H + (unit_ok ? j0 + m : 0)) * K;
-#pragma unroll
-        for (int i = 0; i < KBW; ++i) {
-            const int kb = wave + NWP * i;
-            wreg[i] = (unit_ok && kb < nkb) ? *reinterpret_cast<const f32x4*>(row + kb * 16 + q * 4)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    // gate role: unit jj, local batch row 16 gbt + nn  (512 threads = 16 units x 32 rows)
-    const int jj = tid & 15, nn = (tid >> 4) & 15, gbt = tid >> 8;
-    const int lb = gbt * 16 + nn, gb = b0 + lb, gj = j0 + jj;
-    const bool gate_ok = (gbt < NBT) && (lb < nb) && (gj < H);
-    float dhz = 0.f;                                    // dh * z carried to the next (earlier) step
-    unsigned int* shards = &sync->arrive[dir][part][0][0];
-    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
-    __syncthreads();
-
-    // Round 4 (as in the 4x4x1 kernels): the saved activations of step s + 1 are loaded at the END of step s, behind the
-    // saved-activation stores, not at the top of step s + 1 in front of its hand-off loads
-    float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f;
-    auto load_saved = [&](int t) {
-        dh = r = z = n = gn = hpv = 0.f;
-        if (gate_ok) {
-            const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
-            const size_t row = ((size_t)t * B + gb) * 2 + dir, gbase = row * 3 * H + gj;
-            dh = d_out[((size_t)t * B + gb) * H + gj];
-            r = G[gbase];
-            z = G[gbase + H];
-            n = G[gbase + 2 * H];
-            gn = ghn[row * H + gj];
-            if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
-        }
-    };
-    load_saved(dir == 0 ? T - 1 : 0);
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? T - 1 - s : s;
-        float sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
-        const size_t row = ((size_t)t * B + gb) * 2 + dir, gbase = row * 3 * H + gj;
-        if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
-                abort_flag = 1;
-            __syncthreads();
-            if (abort_flag) return;
-            // d(gh) of the previous step of this (direction, part): [batch tile][k block][k quad 4][16 batch rows][4 k]
-            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-                my_ring + (size_t)((s - 1) & 1) * slot_floats, 0, slot_floats * 4, 0x00020000);
-            constexpr int CH = KBW > 10 ? 7 : KBW;     // stages = (batch tile, k chunk)
-            constexpr int NCH = (KBW + CH - 1) / CH;
-            constexpr int NST = NBT * NCH;
-            f32x4 bf[2][CH];
-            auto fetch = [&](int st, f32x4 (&dst)[CH]) {
-                const int bt = st / NCH, i0 = (st % NCH) * CH;
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int i = i0 + c;
-                    const int kb = wave + NWP * i;                 // wave-uniform
-                    if (i < KBW)                                   // compile-time
-                        dst[c] = LOAD_HANDOFF(rs_x, (kb < nkb) ? ((bt * nkb + kb) * 256 + lane * 4) * 4 : OOB_OFFSET);
-                    else
-                        dst[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            };
-            if (!DS2_DBG(dbg, 2)) {
-                fetch(0, bf[0]);
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int st = 0; st < NST; ++st) {
-                    if (st + 1 < NST) fetch(st + 1, bf[(st + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);   // loads out before the MFMAs
-                    const int bt = st / NCH, i0 = (st % NCH) * CH;
-#pragma unroll
-                    for (int c = 0; c < CH; ++c)
-                        if (i0 + c < KBW) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i0 + c][e], bf[st & 1][c][e], acc, 0, 0, 0);
-                        }
-                    if ((st % NCH) == NCH - 1) {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) red[wave][bt][4 * q + rr][m] = acc[rr];
-                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (gate_ok) {
-            if (s > 0) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < NWP; ++w) a += red[w][gbt][jj][nn];
-                dh += a + dhz;
-            }
-            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
-            const float dz_pre = dh * (hpv - n) * z * (1.f - z);
-            const float dr_pre = dn_pre * gn * r * (1.f - r);
-            dhz = dh * z;
-            sv_r = dr_pre;
-            sv_z = dz_pre;
-            sv_n = dn_pre;
-            sv_g = dn_pre * r;
-        }
-        {   // hand-off copies into the ring (write-through); k index of unit j in gate g is g*H + j.  Quads of gate threads
-            // (units 4u .. 4u+3 of one batch row) gather their values into ONE 16-byte store per gate, as in the forward twin.
-            float q3[3][4];
-#define DS2_QUAD_BCAST(J)                                                                                              \
-    q3[0][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_r), (J) * 0x55, 0xF, 0xF, true));        \
-    q3[1][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_z), (J) * 0x55, 0xF, 0xF, true));        \
-    q3[2][J] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv_g), (J) * 0x55, 0xF, 0xF, true));
-            DS2_QUAD_BCAST(0)
-            DS2_QUAD_BCAST(1)
-            DS2_QUAD_BCAST(2)
-            DS2_QUAD_BCAST(3)
-#undef DS2_QUAD_BCAST
-            if (gate_ok && (jj & 3) == 0) {
-                const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, 2 * slot_floats * 4, 0x00020000);
-                const int sbase = (s & 1) * slot_floats + gbt * nkb * 256 + nn * 4;
-#pragma unroll
-                for (int g3 = 0; g3 < 3; ++g3) {
-                    const int k = g3 * H + gj;
-                    const f32x4 v = {q3[g3][0], q3[g3][1], q3[g3][2], q3[g3][3]};
-                    store_sc1_b128(rs_w, (sbase + (k >> 4) * 256 + ((k & 15) >> 2) * 64) * 4, __builtin_bit_cast(u32x4, v));
-                }
-            }
-        }
-        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
-            G[gbase] = sv_r;
-            G[gbase + H] = sv_z;
-            G[gbase + 2 * H] = sv_n;
-            ghn[row * H + gj] = sv_g;
-        }
-        if (s + 1 < T) load_saved(dir == 0 ? T - 2 - s : s + 1);
-    }
-    if (tid == 0) leave_kernel(sync);
-}
-
-// Backward twin of gru_fwd_persistent_p2b_kernel: K = 3 H (d(gh) of the previous step in the ring, as three bf16 planes),
-// rows of w_hh_t split into registers once.  The hand-off fragments of a batch tile are fetched in chunks of CH k blocks
-// (the weights take 12 registers per block, a chunk of fragments 12 per block too).
-template <int NBT, int KBW>
-__global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent_p2b_kernel(float* __restrict__ G, float* __restrict__ ghn,
-                                                                          const float* __restrict__ hout,
-                                                                          const float* __restrict__ d_out,
-                                                                          const float* __restrict__ w_hh_t,
-                                                                          SyncWs* __restrict__ sync, float* __restrict__ ring,
-                                                                          int T, int B, int H, int dbg) {
-    __shared__ float red[NWP][NBT][16][17];
-    __shared__ int abort_flag;
-    constexpr int UNITS = 16;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dir = blockIdx.y, part = blockIdx.z, nslice = gridDim.x;
-    const int j0 = blockIdx.x * UNITS;
-    const int m = lane & 15, q = lane >> 4;
-    const int K = 3 * H, nkb = K >> 5;                  // k blocks of 32
-    const int bper = (B + 1) / 2, b0 = part * bper, nb = min(bper, B - b0);
-    if (nb <= 0) {
-        if (tid == 0) leave_kernel(sync);
-        return;
-    }
-    const int slot_bytes = NBT * nkb * 3 * 1024;
-    char* my_ring = reinterpret_cast<char*>(ring) + (size_t)(dir * 2 + part) * 2 * slot_bytes;
-    if (tid == 0) abort_flag = 0;
-
-    gbf16x8 wq[KBW][3];                                 // row m: column (j0 + m) of W_hh = row of w_hh_t, k = 32 kb + 8 q ..
-    {
-        const bool unit_ok = (j0 + m) < H;
-        const float* row = w_hh_t + ((size_t)dir * H + (unit_ok ? j0 + m : 0)) * K;
-#pragma unroll
-        for (int i = 0; i < KBW; ++i) {
-            const int kb = wave + NWP * i;
-            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-            if (kb < nkb && unit_ok) {
-                lo = *reinterpret_cast<const f32x4*>(row + kb * 32 + q * 8);
-                hi = *reinterpret_cast<const f32x4*>(row + kb * 32 + q * 8 + 4);
-            }
-            unsigned int pl[3][4];
-            split3(lo[0], lo[1], pl[0][0], pl[1][0], pl[2][0]);
-            split3(lo[2], lo[3], pl[0][1], pl[1][1], pl[2][1]);
-            split3(hi[0], hi[1], pl[0][2], pl[1][2], pl[2][2]);
-            split3(hi[2], hi[3], pl[0][3], pl[1][3], pl[2][3]);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const u32x4 v = {pl[c][0], pl[c][1], pl[c][2], pl[c][3]};
-                wq[i][c] = __builtin_bit_cast(gbf16x8, v);
-            }
-        }
-    }
-    const int jj = tid & 15, nn = (tid >> 4) & 15, gbt = tid >> 8;
-    const int lb = gbt * 16 + nn, gb = b0 + lb, gj = j0 + jj;
-    const bool gate_ok = (gbt < NBT) && (lb < nb) && (gj < H);
-    float dhz = 0.f;                                    // dh * z carried to the next (earlier) step
-    unsigned int* shards = &sync->arrive[dir][part][0][0];
-    unsigned int* ctr = shards + (blockIdx.x % NSHARD) * 32;
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? T - 1 - s : s;
-        const bool has_prev = dir == 0 ? (t > 0) : (t < T - 1);
-        float dh = 0.f, r = 0.f, z = 0.f, n = 0.f, gn = 0.f, hpv = 0.f, sv_r = 0.f, sv_z = 0.f, sv_n = 0.f, sv_g = 0.f;
-        size_t row = 0, gbase = 0;
-        if (gate_ok) {                                  // saved activations of step t: plain loads, issued before the wait
-            row = ((size_t)t * B + gb) * 2 + dir;
-            gbase = row * 3 * H + gj;
-            dh = d_out[((size_t)t * B + gb) * H + gj];
-            r = G[gbase];
-            z = G[gbase + H];
-            n = G[gbase + 2 * H];
-            gn = ghn[row * H + gj];
-            if (has_prev) hpv = hout[(((size_t)dir * T + (dir == 0 ? t - 1 : t + 1)) * B + gb) * H + gj];
-        }
-        if (s > 0) {
-            if (!DS2_DBG(dbg, 1) && wave == 0 && !wait_arrivals(shards, s, nslice, lane, &sync->error) && lane == 0)
-                abort_flag = 1;
-            __syncthreads();
-            if (abort_flag) return;
-            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-                my_ring + (size_t)((s - 1) & 1) * slot_bytes, 0, slot_bytes, 0x00020000);
-            constexpr int CH = KBW > 2 ? 2 : KBW;      // stages = (batch tile, k chunk), double-buffered
-            constexpr int NCH = (KBW + CH - 1) / CH;
-            constexpr int NST = NBT * NCH;
-            if (!DS2_DBG(dbg, 2)) {
-                gbf16x8 bf[2][CH][3];
-                auto fetch = [&](int st, gbf16x8 (&dst)[CH][3]) {
-                    const int bt = st / NCH, i0 = (st % NCH) * CH;
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const int i = i0 + c;
-                        const int kb = wave + NWP * i;                 // wave-uniform
-#pragma unroll
-                        for (int pq = 0; pq < 3; ++pq)
-                            dst[c][pq] = __builtin_bit_cast(
-                                gbf16x8, LOAD_HANDOFF(rs_x, (i < KBW && kb < nkb) ? ((bt * nkb + kb) * 3 + pq) * 1024 + lane * 16
-                                                                                  : OOB_OFFSET));
-                    }
-                };
-                fetch(0, bf[0]);
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int st = 0; st < NST; ++st) {
-                    if (st + 1 < NST) fetch(st + 1, bf[(st + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);                 // loads out before the MFMAs
-                    const int bt = st / NCH, i0 = (st % NCH) * CH;
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const int i = i0 + c;
-                        if (i < KBW) {
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][1], bf[st & 1][c][1], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][0], bf[st & 1][c][2], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][2], bf[st & 1][c][0], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][0], bf[st & 1][c][1], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][1], bf[st & 1][c][0], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i][0], bf[st & 1][c][0], acc, 0, 0, 0);
-                        }
-                    }
-                    if ((st % NCH) == NCH - 1) {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) red[wave][bt][4 * q + rr][m] = acc[rr];
-                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (gate_ok) {
-            if (s > 0) {
-                float a = 0.f;
-#pragma unroll
-                for (int w = 0; w < NWP; ++w) a += red[w][gbt][jj][nn];
-                dh += a + dhz;
-            }
-            const float dn_pre = dh * (1.f - z) * (1.f - n * n);
-            const float dz_pre = dh * (hpv - n) * z * (1.f - z);
-            const float dr_pre = dn_pre * gn * r * (1.f - r);
-            dhz = dh * z;
-            sv_r = dr_pre;
-            sv_z = dz_pre;
-            sv_n = dn_pre;
-            sv_g = dn_pre * r;
-        }
-        {   // hand-off: k index of unit j in gate g is g * H + j (H % 32 == 0: an octet of units is an octet of k)
-            const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(my_ring, 0, 2 * slot_bytes, 0x00020000);
-            const int sbase = (s & 1) * slot_bytes + gbt * nkb * 3 * 1024 + nn * 16;
-            const bool storer = gate_ok && (jj & 7) == 0;
-            auto hand_off = [&](float v, int g3) {                     // (one gate at a time: 12 registers, not 36)
-                u32x4 pl[3];
-                split_gather_octet(v, pl);
-                if (storer) {
-                    const int k = g3 * H + gj;
-                    const int base = sbase + (k >> 5) * 3 * 1024 + ((k & 31) >> 3) * 256;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) store_sc1_b128(rs_w, base + c * 1024, pl[c]);
-                }
-            };
-            hand_off(sv_r, 0);
-            hand_off(sv_z, 1);
-            hand_off(sv_g, 2);
-        }
-        if (!DS2_DBG(dbg, 4)) wait_vmcnt0();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gate_ok) {   // d(gi), d(gh_n) for the GEMMs that follow this launch: plain stores, off the critical path
-            G[gbase] = sv_r;
-            G[gbase + H] = sv_z;
-            G[gbase + 2 * H] = sv_n;
-            ghn[row * H + gj] = sv_g;
-        }
-    }
-    if (tid == 0) leave_kernel(sync);
-}
 
 // ----------------------------------------------------------------------------------------------------------
 // Backward recurrence on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per instruction).
@@ -3254,145 +2004,6 @@ inline int spec_timing(int bwd, int def_delay = -1, int def_inc = 1, int def_log
     return (delay & 0xFF) | ((backoff & 0xFF) << 8) | ((adaptive & 3) << 16) | ((inc & 3) << 18) | ((log2clean & 7) << 20);
 }
 
-inline int pick_kbw(int need, const int* opts, int nopts) {
-    for (int i = 0; i < nopts; ++i)
-        if (opts[i] >= need) return opts[i];
-    return -1;
-}
-
-template <int NBT>
-bool launch_fwd_persistent(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
-                           int H, int dbg, hipStream_t st) {
-    const int opts[] = {1, 2, 4, 7};
-    const int kbw = pick_kbw(ds2_cdiv(H / 16, NWP), opts, 4);
-    dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
-#define DS2_FWD_CASE(K)                                                                                              \
-    case K:                                                                                                          \
-        if (!grid_is_coresident(&gru_fwd_persistent_kernel<NBT, K>, grid, 0)) return false;                          \
-        hipLaunchKernelGGL((gru_fwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, ring, T, B,  \
-                           H, dbg);                                                                                   \
-        return true;
-    switch (kbw) {
-        DS2_FWD_CASE(1)
-        DS2_FWD_CASE(2)
-        DS2_FWD_CASE(4)
-        DS2_FWD_CASE(7)
-    }
-#undef DS2_FWD_CASE
-    return false;
-}
-
-template <int NBT>
-bool launch_fwd_persistent_p2(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
-                              int H, int dbg, hipStream_t st) {
-    const int opts[] = {1, 2, 4, 7};
-    const int kbw = pick_kbw(ds2_cdiv(H / 16, NWP), opts, 4);
-    dim3 grid(ds2_cdiv(H, 16), 2, 2), block(NWP * 64);
-#define DS2_FWDP2_CASE(K)                                                                                          \
-    case K:                                                                                                        \
-        if (!grid_is_coresident(&gru_fwd_persistent_p2_kernel<NBT, K>, grid, 0)) return false;                     \
-        hipLaunchKernelGGL((gru_fwd_persistent_p2_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, ring,   \
-                           T, B, H, dbg);                                                                          \
-        return true;
-    switch (kbw) {
-        DS2_FWDP2_CASE(1)
-        DS2_FWDP2_CASE(2)
-        DS2_FWDP2_CASE(4)
-        DS2_FWDP2_CASE(7)
-    }
-#undef DS2_FWDP2_CASE
-    return false;
-}
-
-template <int NBT>
-bool launch_fwd_persistent_p2b(float* G, float* ghn, float* hout, const float* w_hh, SyncWs* sync, float* ring, int T, int B,
-                               int H, int dbg, hipStream_t st) {
-    const int opts[] = {1, 2, 4};
-    const int kbw = pick_kbw(ds2_cdiv(H / 32, NWP), opts, 3);
-    dim3 grid(ds2_cdiv(H, 16), 2, 2), block(NWP * 64);
-#define DS2_FWDP2B_CASE(K)                                                                                         \
-    case K:                                                                                                        \
-        if (!grid_is_coresident(&gru_fwd_persistent_p2b_kernel<NBT, K>, grid, 0)) return false;                    \
-        hipLaunchKernelGGL((gru_fwd_persistent_p2b_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, w_hh, sync, ring,  \
-                           T, B, H, dbg);                                                                          \
-        return true;
-    switch (kbw) {
-        DS2_FWDP2B_CASE(1)
-        DS2_FWDP2B_CASE(2)
-        DS2_FWDP2B_CASE(4)
-    }
-#undef DS2_FWDP2B_CASE
-    return false;
-}
-
-template <int NBT>
-bool launch_bwd_persistent(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
-                           SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
-    const int opts[] = {1, 2, 4, 8, 19};
-    const int kbw = pick_kbw(ds2_cdiv(3 * H / 16, NWP), opts, 5);
-    dim3 grid(ds2_cdiv(H, PJU), 2), block(NWP * 64);
-#define DS2_BWD_CASE(K)                                                                                          \
-    case K:                                                                                                      \
-        if (!grid_is_coresident(&gru_bwd_persistent_kernel<NBT, K>, grid, 0)) return false;                      \
-        hipLaunchKernelGGL((gru_bwd_persistent_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, \
-                           sync, ring, T, B, H, dbg);                                                            \
-        return true;
-    switch (kbw) {
-        DS2_BWD_CASE(1)
-        DS2_BWD_CASE(2)
-        DS2_BWD_CASE(4)
-        DS2_BWD_CASE(8)
-        DS2_BWD_CASE(19)
-    }
-#undef DS2_BWD_CASE
-    return false;
-}
-
-template <int NBT>
-bool launch_bwd_persistent_p2(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
-                              SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
-    const int opts[] = {1, 2, 4, 8, 19};
-    const int kbw = pick_kbw(ds2_cdiv(3 * H / 16, NWP), opts, 5);
-    dim3 grid(ds2_cdiv(H, 16), 2, 2), block(NWP * 64);
-#define DS2_BWDP2_CASE(K)                                                                                          \
-    case K:                                                                                                        \
-        if (!grid_is_coresident(&gru_bwd_persistent_p2_kernel<NBT, K>, grid, 0)) return false;                     \
-        hipLaunchKernelGGL((gru_bwd_persistent_p2_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, \
-                           sync, ring, T, B, H, dbg);                                                              \
-        return true;
-    switch (kbw) {
-        DS2_BWDP2_CASE(1)
-        DS2_BWDP2_CASE(2)
-        DS2_BWDP2_CASE(4)
-        DS2_BWDP2_CASE(8)
-        DS2_BWDP2_CASE(19)
-    }
-#undef DS2_BWDP2_CASE
-    return false;
-}
-
-template <int NBT>
-bool launch_bwd_persistent_p2b(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
-                               SyncWs* sync, float* ring, int T, int B, int H, int dbg, hipStream_t st) {
-    const int opts[] = {1, 2, 5, 10};
-    const int kbw = pick_kbw(ds2_cdiv(3 * H / 32, NWP), opts, 4);
-    dim3 grid(ds2_cdiv(H, 16), 2, 2), block(NWP * 64);
-#define DS2_BWDP2B_CASE(K)                                                                                          \
-    case K:                                                                                                         \
-        if (!grid_is_coresident(&gru_bwd_persistent_p2b_kernel<NBT, K>, grid, 0)) return false;                     \
-        hipLaunchKernelGGL((gru_bwd_persistent_p2b_kernel<NBT, K>), grid, block, 0, st, G, ghn, hout, d_out, w_hh_t, \
-                           sync, ring, T, B, H, dbg);                                                               \
-        return true;
-    switch (kbw) {
-        DS2_BWDP2B_CASE(1)
-        DS2_BWDP2B_CASE(2)
-        DS2_BWDP2B_CASE(5)
-        DS2_BWDP2B_CASE(10)
-    }
-#undef DS2_BWDP2B_CASE
-    return false;
-}
-
 // The k-balanced deal of the forward 4x4x1 kernel (see the kernel): for which shapes it is built and selected.  KPL = H / 32
 // k per lane row; the speculative single-quad case only (one batch quad per workgroup: B <= 12 with three parts, <= 8 with two);
 // the row's last block must hold whole dwordx4 loads.  DS2_GRU_FWD_KBAL=0 switches it off (A/B timing).
@@ -3556,52 +2167,6 @@ bool launch_bwd_persistent6(float* G, float* ghn, const float* hout, const float
     return true;
 }
 
-// Co-residency: every workgroup of a persistent launch spins on arrivals from all the others, so the whole grid must be
-// on the chip at once.  The budget is 15/16 of the CURRENT device's compute units (240 of an MI355X's 256: the rest
-// stays free for a concurrent RCCL kernel or the side stream), read once per device; a partitioned (CPX) or smaller
-// device simply answers "unsupported" and the caller uses the per-step kernels.
-inline int device_cus() {
-    static int cus[64] = {0};                          // immutable once filled; a race writes the same value twice
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        cus[dev] = n;
-    }
-    return cus[dev];
-}
-inline int max_persistent_wgs() {
-    const int n = device_cus();
-    return n - n / 16;
-}
-
-// Launch-time check of the kernel actually chosen: blocks per CU for its register / LDS footprint x CUs >= grid.
-// Answers are cached per (kernel, LDS bytes, device) -- the occupancy query costs tens of microseconds.
-template <typename K>
-inline bool grid_is_coresident(K kernel, dim3 grid, size_t lds) {
-    struct Entry { const void* k; size_t lds; int dev; int per_cu; };
-    static Entry cache[64];
-    static int ncache = 0;
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    const void* key = reinterpret_cast<const void*>(kernel);
-    int per_cu = -1;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        for (int i = 0; i < ncache; ++i)
-            if (cache[i].k == key && cache[i].lds == lds && cache[i].dev == dev) per_cu = cache[i].per_cu;
-        if (per_cu < 0) {
-            int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NWP * 64, lds) != hipSuccess) n = 0;
-            per_cu = n;
-            if (ncache < 64) cache[ncache++] = Entry{key, lds, dev, n};
-        }
-    }
-    return (long)grid.x * grid.y * grid.z <= (long)per_cu * device_cus();
-}
-
 inline bool persistent_ok(int B, int H) {
     return (H % 16 == 0) && (2 * ds2_cdiv(H, PJU) <= max_persistent_wgs()) && (B <= 64) &&
            (ds2_cdiv(3 * H / 16, NWP) <= 19) && (ds2_cdiv(H / 16, NWP) <= 7);
@@ -3738,13 +2303,13 @@ extern "C" int ds2_gru_bidir_fwd_persistent_ex(float* G, float* ghn, float* hout
     // (round 4, us per step at H = 800: the split-operand two-part form costs 3.32-3.36 whatever B <= 32 is; the whole-batch
     // 16x16x4 form 3.63 at B = 16 -- so the split form takes over as soon as the 4x4x1 forms end, at B = 13)
     else if ((ds2_tune_env("DS2_GRU_FWD_P2") ? ds2_tune_env("DS2_GRU_FWD_P2")[0] == '1' : B >= (p2_bf16(H) ? 13 : 17)) && B >= 2 && H % 16 == 0)
-        ok = p2_bf16(H) ? ((B + 1) / 2 <= 16 ? launch_fwd_persistent_p2b<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
-                                             : launch_fwd_persistent_p2b<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
-                        : ((B + 1) / 2 <= 16 ? launch_fwd_persistent_p2<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
-                                             : launch_fwd_persistent_p2<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st));
-    else if (B <= 16) ok = launch_fwd_persistent<1>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
-    else if (B <= 32) ok = launch_fwd_persistent<2>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
-    else ok = launch_fwd_persistent<4>(G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+        ok = p2_bf16(H) ? ((B + 1) / 2 <= 16 ? ds2_p16_launch_fwd(2, 1, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
+                                             : ds2_p16_launch_fwd(2, 2, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st))
+                        : ((B + 1) / 2 <= 16 ? ds2_p16_launch_fwd(1, 1, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st)
+                                             : ds2_p16_launch_fwd(1, 2, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st));
+    else if (B <= 16) ok = ds2_p16_launch_fwd(0, 1, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    else if (B <= 32) ok = ds2_p16_launch_fwd(0, 2, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
+    else ok = ds2_p16_launch_fwd(0, 4, G, ghn, hout, w_hh, sync, ring, T, B, H, dbg, st);
     if (!ok) {
         ds2_set_error("ds2_gru_bidir_fwd_persistent: the chosen kernel's grid is not co-resident on this device (B=%d H=%d)", B, H);
         return DS2_ERR_UNSUPPORTED;
@@ -3825,10 +2390,10 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
         // they are 1.5 x the bytes: 4.91 against 4.74 us per step at B = 32, 8.46 against 7.57 at B = 64; DS2_GRU_P2_BF16_BWD=1
         // selects it for A/B runs)
         ok = (p2_bf16(H) && getenv("DS2_GRU_P2_BF16_BWD") && getenv("DS2_GRU_P2_BF16_BWD")[0] == '1')
-                 ? ((B + 1) / 2 <= 16 ? launch_bwd_persistent_p2b<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
-                                      : launch_bwd_persistent_p2b<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
-                 : ((B + 1) / 2 <= 16 ? launch_bwd_persistent_p2<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
-                                      : launch_bwd_persistent_p2<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st));
+                 ? ((B + 1) / 2 <= 16 ? ds2_p16_launch_bwd(2, 1, G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
+                                      : ds2_p16_launch_bwd(2, 2, G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st))
+                 : ((B + 1) / 2 <= 16 ? ds2_p16_launch_bwd(1, 1, G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st)
+                                      : ds2_p16_launch_bwd(1, 2, G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st));
     else if (use4 && ngi_ok && parts == 3 && proto != 0 && ds2_cdiv(B, 3) <= 4) {   // (<= 4: also under a forced DS2_GRU_PROTO)
         // units per workgroup by the CUs to leave free (see above); DS2_GRU_BWD_WIDE = 0 / 1 / 2 forces 24 / 28 / 20 (A/B timing)
         const int cus = device_cus();
@@ -3856,9 +2421,9 @@ extern "C" int ds2_gru_bidir_bwd_persistent_ex(float* G, float* ghn, const float
         ok = launch_bwd_persistent5<4, 2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     else if (use4 && ngi_ok && parts == 2) ok = DS2_BWD4_GO(4);
     else if (use4 && ngi_ok) ok = DS2_BWD4_GO(2);
-    else if (B <= 16) ok = launch_bwd_persistent<1>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-    else if (B <= 32) ok = launch_bwd_persistent<2>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
-    else ok = launch_bwd_persistent<4>(G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else if (B <= 16) ok = ds2_p16_launch_bwd(0, 1, G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else if (B <= 32) ok = ds2_p16_launch_bwd(0, 2, G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
+    else ok = ds2_p16_launch_bwd(0, 4, G, ghn, hout, d_out, w_hh_t, sync, ring, T, B, H, dbg, st);
     if (!ok) {
         ds2_set_error("ds2_gru_bidir_bwd_persistent: the chosen kernel's grid is not co-resident on this device (B=%d H=%d)", B, H);
         return DS2_ERR_UNSUPPORTED;
