@@ -23,9 +23,13 @@ namespace {
 
 constexpr int NWP = 8;                    // waves per persistent workgroup (2 per SIMD)
 constexpr int PJU = 8;                    // hidden units per workgroup
+#ifdef DS2_FAULT_INJECT
+constexpr unsigned long long SPIN_TICKS = 150000000ull;  // (the fault-injection build, whose tests WAIT for a time-out: 1.5 s)
+#else
 constexpr unsigned long long SPIN_TICKS = 500000000ull;  // 5 s of the 100 MHz real-time counter: long enough to
                                                          // sit out a peer workgroup that is waiting for CUs held by
                                                          // a concurrent RCCL kernel, short enough to end a lost run
+#endif
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

@@ -54,7 +54,7 @@ def main():
     fwd() if which == 'fwd' else bwd(good_f)
     torch.cuda.synchronize()
     took = time.time() - t0
-    assert 3.0 < took < 60.0, took
+    assert 1.0 < took < 60.0, took             # (the fault-injection build's spins time out after 1.5 s; the release library's after 5)
     os.environ['DS2_GRU_DBG'] = '0'
     # a LATER launch must not erase the flag (round-1 bug: the per-launch memset cleared it): a training step makes ten
     # launches and checks once

@@ -806,7 +806,7 @@ def test_clip_sgd_matches_torch(ops):
 @pytest.mark.parametrize('which', ['fwd', 'bwd'])
 def test_gru_persistent_lost_arrival_times_out_instead_of_hanging(which):
     """Every spin in the persistent kernels is bounded: with one workgroup's arrival suppressed the launch ends after
-    the 5 s timeout, the STICKY flag survives later launches until the host checks it, the device falls back to the
+    the timeout (5 s in the release library, 1.5 s in the fault-injection build this test runs), the STICKY flag survives later launches until the host checks it, the device falls back to the
     per-step kernels for later launches, and after the host's reset the persistent kernels work again.  Runs against
     the fault-injection build in a fresh process (tests/fault_inject_worker.py); the release library has no such hook."""
     import subprocess
