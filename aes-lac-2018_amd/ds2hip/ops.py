@@ -464,13 +464,21 @@ def check_async_errors():
             raise_async_error()
 
 
+_dh_supported = {}
+
+
 def gru_bwd_dh_wanted(dev, bsz, hid):
     """Will ``gru_bidir_bwd`` run the d(h)-hand-off backward recurrence for this shape (so that the training forward pass
     should ask for the coefficient planes)?  Default: where the library has the form AND the forward kernel writes the planes
     itself (B = 9 .. 12 at H = 800: measured stand-alone at B = 10, us per step, d(gh) -> d(h) hand-off: 2.55 -> 2.36 on 240
     workgroups, 2.81 -> 2.67 on 174); for B = 5 .. 8 the planes would cost an extra elementwise pass that eats the
     0.03 us per step the form gains there.  ``DS2_GRU_BWD_DH`` = 0 / 1 forces it off / on wherever the form exists."""
-    if not _use_persistent(dev, bsz, hid) or not lib.query('ds2_gru_bwd_dh_supported', bsz, hid):
+    if not _use_persistent(dev, bsz, hid):
+        return False
+    key = (bsz, hid)
+    if key not in _dh_supported:                      # (a shape's answer never changes: one library query per shape)
+        _dh_supported[key] = bool(lib.query('ds2_gru_bwd_dh_supported', bsz, hid))
+    if not _dh_supported[key]:
         return False
     e = os.environ.get('DS2_GRU_BWD_DH')
     if e in ('0', '1'):
