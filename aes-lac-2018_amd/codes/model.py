@@ -369,10 +369,12 @@ class DeepSpeech(nn.Module):
             if side is not main:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
-                for li, layer in enumerate(self.rnns):
-                    w_hh = self._pair(layer.rnn.weight_hh_l0, layer.rnn.weight_hh_l0_reverse).view(2, 3 * hid, hid)
-                    ops.transpose2d(w_hh[0], 3 * hid, hid, out=wt[li, 0])
-                    ops.transpose2d(w_hh[1], 3 * hid, hid, out=wt[li, 1])
+                # (one launch per 8 layers instead of two per layer: ten ~8-us launches sat in the host's path right at the
+                # start of the step, where the GPU waits for the host)
+                pairs = [self._pair(layer.rnn.weight_hh_l0, layer.rnn.weight_hh_l0_reverse).view(2, 3 * hid, hid)
+                         for layer in self.rnns]
+                for lo in range(0, nlayers, 8):
+                    ops.transpose2d_group(pairs[lo:lo + 8], 2, 3 * hid, hid, wt[lo:lo + 8])
                 ready = torch.cuda.Event()
                 ready.record()
             sv['w_hh_t'], sv['w_hh_t_ready'] = wt, ready

@@ -23,6 +23,29 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// the same for up to 8 separately placed inputs of `batch` matrices each, ONE launch: out is [input][batch][cols][rows]
+struct TransposeGroup { const float* in[8]; };
+__global__ __launch_bounds__(256) void transpose_group_kernel(TransposeGroup g, int batch, int rows, int cols,
+                                                              float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int which = blockIdx.z / batch, b = blockIdx.z % batch;
+    const float* __restrict__ in = g.in[which] + (size_t)b * rows * cols;
+    float* __restrict__ o = out + (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + i][tx] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (r < rows && c < cols) o[(size_t)c * rows + r] = tile[tx][ty + i];
+    }
+}
+
 // one wave per row, A <= 64 * 4
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int rows, int A,
                                                            float* __restrict__ y) {
@@ -130,6 +153,18 @@ extern "C" int ds2_transpose2d(const float* in, int rows, int cols, float* out, 
     DS2_CHECK_ARG(in && out && rows > 0 && cols > 0);
     dim3 grid(ds2_cdiv(cols, 32), ds2_cdiv(rows, 32), 1);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, rows, cols, out);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+}
+
+extern "C" int ds2_transpose2d_group(int count, const float* const* in_host, int batch, int rows, int cols, float* out,
+                                     void* stream) {
+    DS2_CHECK_ARG(in_host && out && count >= 1 && count <= 8 && batch >= 1 && rows > 0 && cols > 0 && count * batch <= 65535);
+    TransposeGroup g;
+    for (int i = 0; i < 8; ++i) g.in[i] = in_host[i < count ? i : 0];
+    for (int i = 0; i < count; ++i) DS2_CHECK_ARG(in_host[i] != nullptr);
+    dim3 grid(ds2_cdiv(cols, 32), ds2_cdiv(rows, 32), count * batch);
+    hipLaunchKernelGGL(transpose_group_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, batch, rows, cols, out);
     DS2_CHECK_LAUNCH();
     return DS2_OK;
 }

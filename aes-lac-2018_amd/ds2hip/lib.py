@@ -50,6 +50,7 @@ SIGNATURES = {
     'ds2_gru_bidir_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     'ds2_gru_bidir_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'ds2_transpose2d': (_I, [_P, _I, _I, _P, _P]),
+    'ds2_transpose2d_group': (_I, [_I, _P, _I, _I, _I, _P, _P]),
     'ds2_gru_sync_ws_bytes': (_Z, [_I, _I]),
     'ds2_gru_sync_error_offset': (_Z, []),
     'ds2_gru_persistent_supported': (_I, [_I, _I]),

@@ -299,6 +299,21 @@ def transpose2d(x, rows, cols, out=None):
     return out
 
 
+def transpose2d_group(tensors, batch, rows, cols, out):
+    """``tensors``: up to 8 device tensors of ``batch`` row-major (rows, cols) matrices each -> out (len, batch, cols, rows), ONE
+    launch (ds2_transpose2d_group)."""
+    import ctypes
+    cnt = len(tensors)
+    assert 1 <= cnt <= 8 and all(t.is_cuda and t.is_contiguous() and t.numel() == batch * rows * cols for t in tensors)
+    assert out.is_cuda and out.is_contiguous() and out.numel() == cnt * batch * rows * cols
+    ptrs = (ctypes.c_void_p * cnt)(*[t.data_ptr() for t in tensors])
+    rc = lib.load().ds2_transpose2d_group(cnt, ctypes.cast(ptrs, ctypes.c_void_p), int(batch), int(rows), int(cols),
+                                          out.data_ptr(), lib.stream_ptr())
+    if rc != 0:
+        raise lib.Ds2Error(rc, 'ds2_transpose2d_group failed (%d): %s' % (rc, lib.load().ds2_last_error().decode()))
+    return out
+
+
 def add2(a, b):
     out = torch.empty_like(a)
     lib.call('ds2_add2', a, b, a.numel(), out)

@@ -207,6 +207,11 @@ int ds2_gru_bidir_fwd(float* G, float* ghn, float* hout, const float* w_hh, int 
 int ds2_gru_bidir_bwd(float* G, float* ghn, const float* hout, const float* d_out, const float* w_hh_t,
                       float* dh_ws, int T, int B, int H, void* stream);
 int ds2_transpose2d(const float* in, int rows, int cols, float* out, void* stream);
+/* The same for `count` (<= 8) separately placed inputs of `batch` row-major (rows, cols) matrices each, in ONE launch:
+ * in_host = HOST array of `count` device pointers; out = (count, batch, cols, rows).  The training forward pass transposes the
+ * recurrent weights of all five layers (two directions each, adjacent in the flat parameter buffer) for the backward recurrence
+ * with one call instead of ten (ABI revision 402). */
+int ds2_transpose2d_group(int count, const float* const* in_host, int batch, int rows, int cols, float* out, void* stream);
 /* Persistent form of the two calls above: ONE launch per layer pass; every workgroup keeps its slice
  * of the recurrent weights in registers for all T steps and hands h_t (forward) / d(gh)_t (backward)
  * to the other workgroups of its direction (and batch part) inside the launch: write-through stores

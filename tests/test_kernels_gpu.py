@@ -589,6 +589,18 @@ def test_gru_backward_forms_by_spare_cus_match_step_kernels(ops, monkeypatch, bs
     _long_sequence_case(ops, monkeypatch, bsz, 6, spare_cus=(0, 82, 52))
 
 
+def test_transpose2d_group_matches_single_transposes(ops):
+    """ds2_transpose2d_group: separately placed inputs of `batch` matrices each, one launch (the recurrent weights of all
+    layers for the backward recurrence)."""
+    torch.manual_seed(5)
+    for cnt, batch, rows, cols in ((5, 2, 96, 32), (1, 1, 33, 70), (8, 2, 2400, 800)):
+        xs = [torch.randn(batch, rows, cols).to(DEV) for _ in range(cnt)]
+        out = torch.empty(cnt, batch, cols, rows, device=DEV)
+        ops.transpose2d_group(xs, batch, rows, cols, out)
+        for i, x in enumerate(xs):
+            assert torch.equal(out[i], x.transpose(1, 2).contiguous())
+
+
 def _dh_case(ops, monkeypatch, t, bsz, hid, spare_cus, reps=2, own_coef=True):
     """The d(h)-hand-off backward recurrence (ds2_gru_bidir_bwd_persistent_dh) against the launch-per-step kernels AND against
     the d(gh)-hand-off form on the same forward pass."""
