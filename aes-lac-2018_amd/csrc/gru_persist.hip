@@ -1161,10 +1161,13 @@ __global__ __launch_bounds__(NWP * 64) void gru_bwd_persistent6_kernel(float* __
             v[1] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0x55, 0xF, 0xF, true));
             v[2] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0xAA, 0xF, 0xF, true));
             v[3] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mine_v), 0xFF, 0xF, 0xF, true));
-            // The stores of the PREVIOUS step are complete before this step's payload goes out (see CANARY_BITS): a wave's
-            // vector-memory operations complete in issue order, this step's dh loads were issued behind those stores, and the
-            // matrix phase has consumed them -- no wait of its own.  Ablation builds that can skip the loads or their validation wait.
-            if constexpr (FIRST || NOVAL) wait_vmcnt0();
+            // The stores of the PREVIOUS step (a step old) are complete before this step's payload goes out (see CANARY_BITS).
+            // By now they always are -- a wave's vector-memory operations complete in issue order, this step's dh loads were
+            // issued behind them and the matrix phase has consumed those -- but the protocol's argument should not rest on
+            // that property: the explicit wait stays.  It also covers the coefficient loads issued during the matrix phase,
+            // L2 hits that have long returned: measured 2.68-2.73 with it against 2.68-2.71 us per step without (174
+            // workgroups), 2.41-2.43 against 2.39-2.42 (240).
+            wait_vmcnt0();
             DS2_WTICK(7);
             if (storer) {
                 const bool lose = DS2_DBG(dbg, 64) && s == 2 && blockIdx.x + blockIdx.y + blockIdx.z == 0;
